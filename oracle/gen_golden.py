@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.json from oracle/pyref.py (Python-int arithmetic, seeded).
+
+TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python3 oracle/gen_golden.py
+The fixtures are data (inputs + expected outputs); both the C oracle and the HIP path
+are checked against them byte-for-byte.  All values are hex strings; field elements and
+points use the C-ABI's canonical little-endian limb format (BP_FMT_LE) unless the key
+says `_amcl` (amcl big-endian `04||X||Y` / MODBYTES big-endian).
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pyref as R  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+SEED = 0xB0117E7
+
+
+def h(b):
+    return bytes(b).hex()
+
+
+def fp_le(c, x):
+    return h(x.to_bytes(4 * c.fp_limbs32, "little"))
+
+
+def fr_le(c, x):
+    return h(c.fr_to_le(x))
+
+
+def pt_le(c, P):
+    return h(c.g1_to_le(P))
+
+
+def rand_fp(rng, c):
+    bits = c.p.bit_length()
+    while True:
+        v = 0
+        for i in range((bits + 63) // 64):
+            v |= rng.next() << (64 * i)
+        v &= (1 << bits) - 1
+        if v < c.p:
+            return v
+
+
+def gen_curves():
+    out = {}
+    for c in R.CURVES.values():
+        G = c.g
+        n32 = c.fp_limbs32
+        Rm = 1 << (32 * n32)
+        Rr = 1 << (32 * c.fr_limbs32)
+        out[c.name] = {
+            "curve_id": c.curve_id,
+            "p": hex(c.p), "r": hex(c.r), "b": c.b,
+            "gx": hex(G[0]), "gy": hex(G[1]),
+            "modbytes": c.modbytes, "fp_limbs32": n32, "fr_limbs32": c.fr_limbs32,
+            "fp_inv32": hex((-pow(c.p, -1, 1 << 32)) % (1 << 32)),
+            "fr_inv32": hex((-pow(c.r, -1, 1 << 32)) % (1 << 32)),
+            "fp_inv64": hex((-pow(c.p, -1, 1 << 64)) % (1 << 64)),
+            "fr_inv64": hex((-pow(c.r, -1, 1 << 64)) % (1 << 64)),
+            "fp_R_mod_p": hex(Rm % c.p), "fp_R2_mod_p": hex(Rm * Rm % c.p),
+            "fr_R_mod_r": hex(Rr % c.r), "fr_R2_mod_r": hex(Rr * Rr % c.r),
+            "G": pt_le(c, G), "G2": pt_le(c, c.add(G, G)), "G3": pt_le(c, c.mul(3, G)),
+            "G_rm1": pt_le(c, c.mul(c.r - 1, G)),
+            "G_amcl": h(c.g1_to_bytes(G)), "identity_amcl": h(c.g1_to_bytes(None)),
+        }
+    return out
+
+
+def gen_field():
+    out = {}
+    for c in R.CURVES.values():
+        rng = R.SplitMix64(SEED + 100 + c.curve_id)
+        fp_cases, fr_cases = [], []
+        specials_p = [0, 1, 2, c.p - 1, c.p - 2, (c.p - 1) // 2]
+        specials_r = [0, 1, 2, c.r - 1, c.r - 2, (c.r - 1) // 2]
+        pairs_p = [(a, b) for a in specials_p for b in specials_p] + [(rand_fp(rng, c), rand_fp(rng, c)) for _ in range(64)]
+        pairs_r = [(a, b) for a in specials_r for b in specials_r] + [(rng.scalar(c), rng.scalar(c)) for _ in range(64)]
+        for a, b in pairs_p:
+            fp_cases.append({"a": fp_le(c, a), "b": fp_le(c, b), "add": fp_le(c, (a + b) % c.p), "sub": fp_le(c, (a - b) % c.p),
+                             "mul": fp_le(c, a * b % c.p), "inv_a": fp_le(c, pow(a, -1, c.p) if a else 0)})
+        for a, b in pairs_r:
+            fr_cases.append({"a": fr_le(c, a), "b": fr_le(c, b), "add": fr_le(c, (a + b) % c.r), "sub": fr_le(c, (a - b) % c.r),
+                             "mul": fr_le(c, a * b % c.r), "inv_a": fr_le(c, pow(a, -1, c.r) if a else 0)})
+        out[c.name] = {"fp": fp_cases, "fr": fr_cases}
+    return out
+
+
+def gen_g1():
+    out = {}
+    for c in R.CURVES.values():
+        rng = R.SplitMix64(SEED + 200 + c.curve_id)
+        G = c.g
+        pts = [c.mul(rng.scalar(c), G) for _ in range(6)]
+        adds = []
+        cases = [(None, None), (None, pts[0]), (pts[0], None), (pts[0], pts[0]), (pts[0], c.neg(pts[0])),
+                 (G, G), (G, c.neg(G))] + [(pts[i], pts[j]) for i in range(6) for j in range(i + 1, 6)]
+        for P, Q in cases:
+            adds.append({"p": pt_le(c, P), "q": pt_le(c, Q), "sum": pt_le(c, c.add(P, Q))})
+        muls = []
+        ks = [0, 1, 2, 3, 15, 16, 17, 2**32 - 1, 2**32, 2**64 + 1, c.r - 1, c.r - 2, (c.r + 1) // 2] + [rng.scalar(c) for _ in range(12)]
+        for k in ks:
+            for P in (G, pts[1]):
+                muls.append({"k": fr_le(c, k), "p": pt_le(c, P), "kp": pt_le(c, c.mul(k, P))})
+        muls.append({"k": fr_le(c, 5), "p": pt_le(c, None), "kp": pt_le(c, None)})
+        # a1*P + a2*Q  (binary_scalar_mul, src/ipp.rs:119,125,185,187)
+        bins = []
+        for _ in range(8):
+            k1, k2 = rng.scalar(c), rng.scalar(c)
+            P, Q = pts[rng.next() % 6], pts[rng.next() % 6]
+            bins.append({"k1": fr_le(c, k1), "k2": fr_le(c, k2), "p": pt_le(c, P), "q": pt_le(c, Q),
+                         "out": pt_le(c, c.add(c.mul(k1, P), c.mul(k2, Q)))})
+        P = pts[2]
+        bins.append({"k1": fr_le(c, 7), "k2": fr_le(c, c.r - 7), "p": pt_le(c, P), "q": pt_le(c, P), "out": pt_le(c, None)})
+        bins.append({"k1": fr_le(c, 0), "k2": fr_le(c, 0), "p": pt_le(c, P), "q": pt_le(c, G), "out": pt_le(c, None)})
+        bins.append({"k1": fr_le(c, 1), "k2": fr_le(c, 1), "p": pt_le(c, P), "q": pt_le(c, P), "out": pt_le(c, c.add(P, P))})
+        out[c.name] = {"add": adds, "mul": muls, "binary_scalar_mul": bins}
+    return out
+
+
+def gen_msm():
+    out = {}
+    for c in R.CURVES.values():
+        rng = R.SplitMix64(SEED + 300 + c.curve_id)
+        G = c.g
+        pool = [c.mul(rng.scalar(c), G) for _ in range(300)]
+        cases = []
+
+        def case(name, scalars, points):
+            cases.append({"name": name, "n": len(scalars), "scalars": [fr_le(c, s) for s in scalars],
+                          "points": [pt_le(c, P) for P in points], "out": pt_le(c, c.msm(scalars, points))})
+            print("  msm", c.name, name, len(scalars), file=sys.stderr)
+
+        case("empty", [], [])
+        for n in (1, 2, 3, 17, 64, 257):
+            case("random_%d" % n, [rng.scalar(c) for _ in range(n)], pool[:n])
+        case("all_zero_scalars", [0] * 9, pool[:9])
+        case("some_zero_scalars", [0 if i % 3 == 0 else rng.scalar(c) for i in range(40)], pool[:40])
+        case("all_ones", [1] * 33, pool[:33])
+        case("bits", [rng.next() & 1 for _ in range(100)], pool[:100])                    # config-3-like a_L
+        case("small_scalars", [rng.next() % 1000 for _ in range(64)], pool[:64])
+        case("r_minus_1", [c.r - 1] * 5, pool[:5])
+        case("identity_points", [rng.scalar(c) for _ in range(6)], [None, pool[0], None, pool[1], pool[2], None])
+        case("all_same_point", [rng.scalar(c) for _ in range(50)], [pool[7]] * 50)
+        case("same_point_same_scalar", [12345] * 40, [pool[8]] * 40)                       # forces P+P in buckets
+        case("p_and_minus_p", [5, 5, 7, 7], [pool[3], c.neg(pool[3]), pool[4], c.neg(pool[4])])
+        s = rng.scalar(c)
+        case("cancel_to_identity", [s, c.r - s], [pool[5], pool[5]])
+        # digits that land in the same signed-window bucket with opposite signs, every window size 1..16
+        case("window_edge_scalars", [(1 << k) - 1 for k in range(1, 33)] + [1 << k for k in range(1, 33)] + [(1 << 255) % c.r, c.r >> 1],
+             (pool * 2)[:66])
+        case("duplicates_mixed", [rng.scalar(c) for _ in range(30)], [pool[i % 4] for i in range(30)])
+        out[c.name] = cases
+    return out
+
+
+def gen_merlin():
+    cases = []
+    t = R.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    cases.append({"name": "merlin_conformance_simple", "label": h(b"test protocol"),
+                  "ops": [["append", h(b"some label"), h(b"some data")], ["challenge", h(b"challenge"), 32]],
+                  "challenges": [h(t.challenge_bytes(b"challenge", 32))]})
+    assert cases[0]["challenges"][0] == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    rng = R.SplitMix64(SEED + 400)
+    t = R.Transcript(b"innerproduct")
+    ops, chals = [], []
+    for i in range(12):
+        ln = [0, 1, 7, 48, 97, 164, 165, 166, 167, 200, 400, 1024][i]
+        msg = bytes(rng.next() & 0xFF for _ in range(ln))
+        lab = b"L" if i % 2 else b"some-longer-label"
+        t.append_message(lab, msg)
+        ops.append(["append", h(lab), h(msg)])
+        n = [1, 32, 48, 166, 167, 400][i % 6]
+        ops.append(["challenge", h(b"u"), n])
+        chals.append(h(t.challenge_bytes(b"u", n)))
+    cases.append({"name": "long_mixed", "label": h(b"innerproduct"), "ops": ops, "challenges": chals})
+    return cases
+
+
+def gen_ipp():
+    out = {}
+    for c in R.CURVES.values():
+        rng = R.SplitMix64(SEED + 500 + c.curve_id)
+        G0 = c.g
+        cases = []
+        for name, n, a, b, unit_gf in (
+            ("n1", 1, [3], [9], True),
+            ("n2", 2, [1, 2], [5, 6], True),
+            ("test_ipp_n4", 4, [1, 2, 3, 4], [5, 6, 7, 8], True),                     # src/ipp.rs:325-390
+            ("test_ipp_non_power_of_2_n8", 8, [1, 2, 3, 4, 9, 0, 0, 0], [5, 6, 7, 8, 10, 0, 0, 0], True),  # :393-489
+            ("random_n8_gfactors", 8, None, None, False),
+            ("random_n16", 16, None, None, True),
+        ):
+            if a is None:
+                a = [rng.scalar(c) for _ in range(n)]
+                b = [rng.scalar(c) for _ in range(n)]
+            G = [c.mul(rng.scalar(c), G0) for _ in range(n)]
+            H = [c.mul(rng.scalar(c), G0) for _ in range(n)]
+            Q = c.mul(rng.scalar(c), G0)
+            y_inv = rng.scalar(c)
+            Gf = [1] * n if unit_gf else [rng.scalar(c) for _ in range(n)]
+            Hf = [pow(y_inv, i, c.r) for i in range(n)]                                # new_vandermonde_vector
+            t = R.Transcript(b"innerproduct")
+            Lv, Rv, a0, b0 = R.ipp_create(c, t, Q, Gf, Hf, G, H, a, b)
+            after = t.challenge_bytes(b"after", 32)
+            # P = <a, G*Gf> + <b, H*Hf> + <a,b> Q  (src/ipp.rs:353-372, generalised to G_factors != 1)
+            ip = sum(x * y for x, y in zip(a, b)) % c.r
+            P = c.msm([x * g % c.r for x, g in zip(a, Gf)] + [x * y % c.r for x, y in zip(b, Hf)] + [ip], G + H + [Q])
+            assert R.ipp_verify(c, n, R.Transcript(b"innerproduct"), Gf, Hf, P, Q, G, H, a0, b0, Lv, Rv)
+            assert not R.ipp_verify(c, n, R.Transcript(b"innerproduct"), Gf, Hf, P, Q, G, H, (a0 + 1) % c.r, b0, Lv, Rv)
+            cases.append({
+                "name": name, "n": n,
+                "a": [fr_le(c, x) for x in a], "b": [fr_le(c, x) for x in b],
+                "G": [pt_le(c, X) for X in G], "H": [pt_le(c, X) for X in H], "Q": pt_le(c, Q),
+                "G_factors": [fr_le(c, x) for x in Gf], "H_factors": [fr_le(c, x) for x in Hf],
+                "L": [pt_le(c, X) for X in Lv], "R": [pt_le(c, X) for X in Rv],
+                "L_amcl": [h(c.g1_to_bytes(X)) for X in Lv],
+                "a_out": fr_le(c, a0), "b_out": fr_le(c, b0), "P": pt_le(c, P),
+                "transcript_after": h(after),
+            })
+            print("  ipp", c.name, name, file=sys.stderr)
+        out[c.name] = cases
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, fn in (("curves", gen_curves), ("field", gen_field), ("g1", gen_g1), ("merlin", gen_merlin),
+                     ("msm", gen_msm), ("ipp", gen_ipp)):
+        print("generating", name, file=sys.stderr)
+        with open(os.path.join(OUT, name + ".json"), "w") as f:
+            json.dump(fn(), f, indent=0, sort_keys=True)
+            f.write("\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,203 @@
+/* oracle/orc_api_tmpl.h -- TEST INFRASTRUCTURE ONLY.  Byte-level wrappers (C-ABI canonical LE format)
+ * around the per-curve template code; one instance per curve, dispatched in oracle.c. */
+
+static void C(load_pts)(C(aff_t)* out, const uint8_t* in, size_t n) { for (size_t i = 0; i < n; i++) C(aff_from_le)(&out[i], in + i * 2 * FP_LE_BYTES); }
+static void C(load_frs)(FR(t)* out, const uint8_t* in, size_t n) { for (size_t i = 0; i < n; i++) FR(from_le)(&out[i], in + i * FR_LE_BYTES, FR_LE_BYTES); }
+static void C(load_raw)(uint64_t* out, const uint8_t* in, size_t n) {
+    memset(out, 0, n * FR_NL * 8);
+    for (size_t i = 0; i < n; i++) for (int j = 0; j < FR_LE_BYTES; j++) out[i * FR_NL + j / 8] |= (uint64_t)in[i * FR_LE_BYTES + j] << (8 * (j % 8));
+}
+
+static int C(api_field_op)(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if (which == 0) {
+        FP(t) x, y, z; FP(from_le)(&x, a, FP_LE_BYTES); FP(from_le)(&y, b, FP_LE_BYTES);
+        switch (op) { case 0: FP(add)(&z, &x, &y); break; case 1: FP(sub)(&z, &x, &y); break; case 2: FP(mul)(&z, &x, &y); break; case 3: FP(inv)(&z, &x); break; default: return 2; }
+        FP(to_le)(out, &z, FP_LE_BYTES);
+    } else {
+        FR(t) x, y, z; FR(from_le)(&x, a, FR_LE_BYTES); FR(from_le)(&y, b, FR_LE_BYTES);
+        switch (op) { case 0: FR(add)(&z, &x, &y); break; case 1: FR(sub)(&z, &x, &y); break; case 2: FR(mul)(&z, &x, &y); break; case 3: FR(inv)(&z, &x); break; default: return 2; }
+        FR(to_le)(out, &z, FR_LE_BYTES);
+    }
+    return 0;
+}
+
+static int C(api_on_curve)(const uint8_t* p) { C(aff_t) a; C(aff_from_le)(&a, p); return C(aff_on_curve)(&a); }
+
+static int C(api_g1_add)(const uint8_t* p, const uint8_t* q, uint8_t* out) {
+    C(aff_t) a, b, r; C(aff_from_le)(&a, p); C(aff_from_le)(&b, q);
+    C(jac_t) j; C(jac_from_aff)(&j, &a); C(jac_add_aff)(&j, &j, &b); C(jac_to_aff)(&r, &j); C(aff_to_le)(out, &r);
+    return 0;
+}
+
+static int C(api_g1_mul)(const uint8_t* k, const uint8_t* p, uint8_t* out) {
+    C(aff_t) a, r; C(aff_from_le)(&a, p);
+    uint64_t raw[FR_NL]; C(load_raw)(raw, k, 1);
+    C(jac_t) j; C(jac_mul_raw)(&j, raw, &a); C(jac_to_aff)(&r, &j); C(aff_to_le)(out, &r);
+    return 0;
+}
+
+static int C(api_binary_scalar_mul)(const uint8_t* p, const uint8_t* h, const uint8_t* r1, const uint8_t* r2, uint8_t* out) {
+    C(aff_t) a, b, r; C(aff_from_le)(&a, p); C(aff_from_le)(&b, h);
+    FR(t) k1, k2; FR(from_le)(&k1, r1, FR_LE_BYTES); FR(from_le)(&k2, r2, FR_LE_BYTES);
+    C(binary_scalar_mul)(&r, &a, &b, &k1, &k2); C(aff_to_le)(out, &r);
+    return 0;
+}
+
+/* out[i] = k[i] * G (i < n), batch-normalised; threaded by contiguous slices */
+typedef struct { const uint64_t* ks; C(aff_t)* out; size_t lo, hi; } C(fb_job_t);
+static C(aff_t)* C(fb_table);   /* [64 windows of 4 bits][15] affine multiples of G, built once */
+static void C(fb_build)(void) {
+    if (C(fb_table)) return;
+    int nw = (FR(P).bits + 3) / 4;
+    C(jac_t)* tj = (C(jac_t)*)malloc((size_t)nw * 15 * sizeof(C(jac_t)));
+    C(jac_t) base; C(jac_from_aff)(&base, &C(GEN));
+    for (int w = 0; w < nw; w++) {
+        tj[w * 15] = base;
+        for (int d = 1; d < 15; d++) C(jac_add)(&tj[w * 15 + d], &tj[w * 15 + d - 1], &base);
+        for (int i = 0; i < 4; i++) C(jac_dbl)(&base, &base);
+    }
+    C(aff_t)* ta = (C(aff_t)*)malloc((size_t)nw * 15 * sizeof(C(aff_t)));
+    C(jac_batch_to_aff)(ta, tj, (size_t)nw * 15);
+    free(tj);
+    C(fb_table) = ta;
+}
+static void* C(fb_worker)(void* arg) {
+    C(fb_job_t)* j = (C(fb_job_t)*)arg;
+    size_t n = j->hi - j->lo;
+    int nw = (FR(P).bits + 3) / 4;
+    C(jac_t)* acc = (C(jac_t)*)malloc((n ? n : 1) * sizeof(C(jac_t)));
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t* k = j->ks + (j->lo + i) * FR_NL;
+        C(jac_set_inf)(&acc[i]);
+        for (int w = 0; w < nw; w++) {
+            unsigned d = (unsigned)(k[(4 * w) / 64] >> ((4 * w) % 64)) & 15;
+            if (d) C(jac_add_aff)(&acc[i], &acc[i], &C(fb_table)[w * 15 + d - 1]);
+        }
+    }
+    C(jac_batch_to_aff)(j->out + j->lo, acc, n);
+    free(acc);
+    return 0;
+}
+static int C(api_fixed_base_batch)(const uint8_t* ks, size_t n, int nthreads, uint8_t* out) {
+    C(fb_build)();
+    uint64_t* raw = (uint64_t*)malloc((n ? n : 1) * FR_NL * 8); C(load_raw)(raw, ks, n);
+    C(aff_t)* res = (C(aff_t)*)malloc((n ? n : 1) * sizeof(C(aff_t)));
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t th[64]; C(fb_job_t) jobs[64];
+    if (nthreads > 64) nthreads = 64;
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].ks = raw; jobs[t].out = res; jobs[t].lo = n * (size_t)t / nthreads; jobs[t].hi = n * (size_t)(t + 1) / nthreads;
+        if (nthreads == 1) C(fb_worker)(&jobs[t]); else pthread_create(&th[t], 0, C(fb_worker), &jobs[t]);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; t++) pthread_join(th[t], 0);
+    for (size_t i = 0; i < n; i++) C(aff_to_le)(out + i * 2 * FP_LE_BYTES, &res[i]);
+    free(raw); free(res);
+    return 0;
+}
+
+/* algo: 0 naive, 1 Strauss wNAF-5 (reference-like, single thread), 2 Pippenger (nthreads) */
+static int C(api_msm)(int algo, const uint8_t* pts, const uint8_t* ks, size_t n, int nthreads, uint8_t* out) {
+    C(aff_t)* P = (C(aff_t)*)malloc((n ? n : 1) * sizeof(C(aff_t))); C(load_pts)(P, pts, n);
+    uint64_t* raw = (uint64_t*)malloc((n ? n : 1) * FR_NL * 8); C(load_raw)(raw, ks, n);
+    C(jac_t) j; C(aff_t) r;
+    switch (algo) {
+        case 0: C(msm_naive)(&j, P, raw, n); break;
+        case 1: C(msm_strauss)(&j, P, raw, n); break;
+        case 2: C(msm_pippenger)(&j, P, raw, n, nthreads); break;
+        default: free(P); free(raw); return 2;
+    }
+    C(jac_to_aff)(&r, &j); C(aff_to_le)(out, &r);
+    free(P); free(raw);
+    return 0;
+}
+
+/* Timed variant for bench.py's cpu_baseline leg: conversion from bytes is excluded from the timing,
+ * matching the GPU leg, whose inputs are already resident in Montgomery form. */
+static int C(api_msm_timed)(int algo, const uint8_t* pts, const uint8_t* ks, size_t n, int nthreads, uint8_t* out, double* seconds) {
+    C(aff_t)* P = (C(aff_t)*)malloc((n ? n : 1) * sizeof(C(aff_t))); C(load_pts)(P, pts, n);
+    uint64_t* raw = (uint64_t*)malloc((n ? n : 1) * FR_NL * 8); C(load_raw)(raw, ks, n);
+    C(jac_t) j; C(aff_t) r;
+    struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    switch (algo) {
+        case 0: C(msm_naive)(&j, P, raw, n); break;
+        case 1: C(msm_strauss)(&j, P, raw, n); break;
+        case 2: C(msm_pippenger)(&j, P, raw, n, nthreads); break;
+        default: free(P); free(raw); return 2;
+    }
+    C(jac_to_aff)(&r, &j);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    C(aff_to_le)(out, &r);
+    free(P); free(raw);
+    return 0;
+}
+
+static int C(api_fr_inner)(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    FR(t)* x = (FR(t)*)malloc((n ? n : 1) * sizeof(FR(t))); FR(t)* y = (FR(t)*)malloc((n ? n : 1) * sizeof(FR(t)));
+    C(load_frs)(x, a, n); C(load_frs)(y, b, n);
+    FR(t) r; C(fr_inner)(&r, x, y, n); FR(to_le)(out, &r, FR_LE_BYTES);
+    free(x); free(y);
+    return 0;
+}
+
+/* sum_i a_i * b_i mod r with a_i, b_i canonical LE; used for the full-size linearity check
+ * MSM(s, k.G) == (sum s_i k_i) G */
+static int C(api_ipp_create)(orc_transcript* tr, const uint8_t* Q, const uint8_t* Gf, const uint8_t* Hf, const uint8_t* G, const uint8_t* H,
+                             const uint8_t* a, const uint8_t* b, size_t n, uint8_t* L_out, uint8_t* R_out, uint8_t* a_out, uint8_t* b_out) {
+    if (n == 0 || (n & (n - 1))) return 2;                                                /* assert!(n.is_power_of_two()) :48 */
+    C(aff_t) q; C(aff_from_le)(&q, Q);
+    C(aff_t)* g = (C(aff_t)*)malloc(n * sizeof *g); C(aff_t)* h = (C(aff_t)*)malloc(n * sizeof *h);
+    FR(t)* gf = (FR(t)*)malloc(n * sizeof *gf); FR(t)* hf = (FR(t)*)malloc(n * sizeof *hf);
+    FR(t)* av = (FR(t)*)malloc(n * sizeof *av); FR(t)* bv = (FR(t)*)malloc(n * sizeof *bv);
+    C(load_pts)(g, G, n); C(load_pts)(h, H, n); C(load_frs)(gf, Gf, n); C(load_frs)(hf, Hf, n); C(load_frs)(av, a, n); C(load_frs)(bv, b, n);
+    C(aff_t) L[64], R[64]; FR(t) a0, b0;
+    int lg = C(ipp_create)(tr, &q, gf, hf, g, h, av, bv, n, L, R, &a0, &b0);
+    for (int i = 0; i < lg; i++) { C(aff_to_le)(L_out + i * 2 * FP_LE_BYTES, &L[i]); C(aff_to_le)(R_out + i * 2 * FP_LE_BYTES, &R[i]); }
+    FR(to_le)(a_out, &a0, FR_LE_BYTES); FR(to_le)(b_out, &b0, FR_LE_BYTES);
+    free(g); free(h); free(gf); free(hf); free(av); free(bv);
+    return 0;
+}
+
+static int C(api_ipp_verify)(orc_transcript* tr, size_t n, const uint8_t* Gf, const uint8_t* Hf, const uint8_t* P, const uint8_t* Q,
+                             const uint8_t* G, const uint8_t* H, const uint8_t* a, const uint8_t* b, const uint8_t* L, const uint8_t* R, size_t lg_n) {
+    if (lg_n >= 32 || n != ((size_t)1 << lg_n)) return 3;
+    C(aff_t) p, q; C(aff_from_le)(&p, P); C(aff_from_le)(&q, Q);
+    C(aff_t)* g = (C(aff_t)*)malloc(n * sizeof *g); C(aff_t)* h = (C(aff_t)*)malloc(n * sizeof *h);
+    FR(t)* gf = (FR(t)*)malloc(n * sizeof *gf); FR(t)* hf = (FR(t)*)malloc(n * sizeof *hf);
+    C(load_pts)(g, G, n); C(load_pts)(h, H, n); C(load_frs)(gf, Gf, n); C(load_frs)(hf, Hf, n);
+    C(aff_t) Lp[64], Rp[64]; C(load_pts)(Lp, L, lg_n); C(load_pts)(Rp, R, lg_n);
+    FR(t) av, bv; FR(from_le)(&av, a, FR_LE_BYTES); FR(from_le)(&bv, b, FR_LE_BYTES);
+    int rc = C(ipp_verify)(tr, n, gf, hf, &p, &q, g, h, &av, &bv, Lp, Rp, lg_n);
+    free(g); free(h); free(gf); free(hf);
+    return rc;
+}
+
+static int C(api_verification_scalars)(orc_transcript* tr, const uint8_t* L, const uint8_t* R, size_t lg_n, size_t n,
+                                       uint8_t* u_sq, uint8_t* u_inv_sq, uint8_t* s) {
+    if (lg_n >= 32 || n != ((size_t)1 << lg_n)) return 3;
+    C(aff_t) Lp[64], Rp[64]; C(load_pts)(Lp, L, lg_n); C(load_pts)(Rp, R, lg_n);
+    FR(t)* sv = (FR(t)*)malloc(n * sizeof *sv); FR(t) us[64], uis[64];
+    int rc = C(ipp_verification_scalars)(tr, Lp, Rp, lg_n, n, us, uis, sv);
+    if (!rc) {
+        for (size_t j = 0; j < lg_n; j++) { FR(to_le)(u_sq + j * FR_LE_BYTES, &us[j], FR_LE_BYTES); FR(to_le)(u_inv_sq + j * FR_LE_BYTES, &uis[j], FR_LE_BYTES); }
+        for (size_t i = 0; i < n; i++) FR(to_le)(s + i * FR_LE_BYTES, &sv[i], FR_LE_BYTES);
+    }
+    free(sv);
+    return rc;
+}
+
+static int C(api_challenge_scalar)(orc_transcript* tr, const char* label, uint8_t* out) {
+    FR(t) u; C(t_challenge_scalar)(tr, label, &u); FR(to_le)(out, &u, FR_LE_BYTES); return 0;
+}
+static int C(api_commit_point)(orc_transcript* tr, const char* label, const uint8_t* p) {
+    C(aff_t) a; C(aff_from_le)(&a, p); C(t_commit_point)(tr, label, &a); return 0;
+}
+
+static void C(api_init)(const uint64_t* p, const uint64_t* r, uint64_t b, const uint64_t* gx, const uint64_t* gy) {
+    FP(init)(p); FR(init)(r);
+    FP(from_u64)(&C(B), b);
+    uint8_t buf[2 * FP_LE_BYTES]; memset(buf, 0, sizeof buf);
+    for (int i = 0; i < FP_LE_BYTES; i++) { buf[i] = (uint8_t)(gx[i / 8] >> (8 * (i % 8))); buf[FP_LE_BYTES + i] = (uint8_t)(gy[i / 8] >> (8 * (i % 8))); }
+    C(aff_from_le)(&C(GEN), buf);
+}

@@ -1,0 +1,178 @@
+"""ctypes binding of oracle/liboracle.so (the CPU oracle) -- the CHECKER used by tests, smoke() and
+bench.py's cpu_baseline leg.  Never imported by the product package."""
+import ctypes
+import os
+import subprocess
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_DIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_DIR, "liboracle.so")
+
+BLS12_381, BN254 = 0, 1
+CURVE_IDS = {"bls12_381": 0, "bn254": 1}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _DIR])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        L.orc_msm_timed.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                    ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+        L.orc_transcript_size.restype = ctypes.c_size_t
+        for name in ("orc_msm", "orc_g1_fixed_base_batch", "orc_fr_inner", "orc_random_scalars", "orc_ipp_create",
+                     "orc_ipp_verify", "orc_ipp_verification_scalars", "orc_transcript_new",
+                     "orc_transcript_append_message", "orc_transcript_challenge_bytes"):
+            getattr(L, name).argtypes = None
+        _lib = L
+    return _lib
+
+
+def fp_bytes(curve):
+    return 48 if curve == 0 else 32
+
+
+def pt_bytes(curve):
+    return 2 * fp_bytes(curve)
+
+
+FR_BYTES = 32
+
+
+def _buf(n):
+    return ctypes.create_string_buffer(n)
+
+
+def field_op(curve, which, op, a, b):
+    n = fp_bytes(curve) if which == 0 else FR_BYTES
+    out = _buf(n)
+    rc = lib().orc_field_op(curve, which, op, bytes(a), bytes(b), out)
+    assert rc == 0
+    return out.raw
+
+
+def on_curve(curve, p):
+    return bool(lib().orc_g1_on_curve(curve, bytes(p)))
+
+
+def generator(curve):
+    out = _buf(pt_bytes(curve))
+    assert lib().orc_g1_generator(curve, out) == 0
+    return out.raw
+
+
+def g1_add(curve, p, q):
+    out = _buf(pt_bytes(curve))
+    assert lib().orc_g1_add(curve, bytes(p), bytes(q), out) == 0
+    return out.raw
+
+
+def g1_mul(curve, k, p):
+    out = _buf(pt_bytes(curve))
+    assert lib().orc_g1_mul(curve, bytes(k), bytes(p), out) == 0
+    return out.raw
+
+
+def binary_scalar_mul(curve, p, h, r1, r2):
+    out = _buf(pt_bytes(curve))
+    assert lib().orc_g1_binary_scalar_mul(curve, bytes(p), bytes(h), bytes(r1), bytes(r2), out) == 0
+    return out.raw
+
+
+def fixed_base_batch(curve, ks, n, nthreads=1):
+    out = _buf(max(1, n) * pt_bytes(curve))
+    assert lib().orc_g1_fixed_base_batch(ctypes.c_int(curve), bytes(ks), ctypes.c_size_t(n), ctypes.c_int(nthreads), out) == 0
+    return out.raw[: n * pt_bytes(curve)]
+
+
+def g1_to_amcl(curve, p):
+    out = _buf(2 * fp_bytes(curve) + 1)
+    assert lib().orc_g1_to_amcl(curve, bytes(p), out) == 0
+    return out.raw
+
+
+NAIVE, STRAUSS, PIPPENGER = 0, 1, 2
+
+
+def msm(curve, points, scalars, n, algo=PIPPENGER, nthreads=1):
+    out = _buf(pt_bytes(curve))
+    rc = lib().orc_msm(ctypes.c_int(curve), ctypes.c_int(algo), bytes(points), bytes(scalars), ctypes.c_size_t(n),
+                       ctypes.c_int(nthreads), out)
+    assert rc == 0
+    return out.raw
+
+
+def msm_timed(curve, points, scalars, n, algo, nthreads=1):
+    out = _buf(pt_bytes(curve))
+    sec = ctypes.c_double(0)
+    rc = lib().orc_msm_timed(curve, algo, bytes(points), bytes(scalars), n, nthreads, out, ctypes.byref(sec))
+    assert rc == 0
+    return out.raw, sec.value
+
+
+def fr_inner(curve, a, b, n):
+    out = _buf(FR_BYTES)
+    assert lib().orc_fr_inner(ctypes.c_int(curve), bytes(a), bytes(b), ctypes.c_size_t(n), out) == 0
+    return out.raw
+
+
+def random_scalars(curve, seed, n):
+    out = _buf(max(1, n) * FR_BYTES)
+    assert lib().orc_random_scalars(ctypes.c_int(curve), ctypes.c_uint64(seed), ctypes.c_size_t(n), out) == 0
+    return out.raw[: n * FR_BYTES]
+
+
+class Transcript:
+    def __init__(self, label: bytes):
+        self.buf = _buf(lib().orc_transcript_size())
+        lib().orc_transcript_new(self.buf, label, ctypes.c_size_t(len(label)))
+
+    def append_message(self, label, msg):
+        lib().orc_transcript_append_message(self.buf, label, ctypes.c_size_t(len(label)), bytes(msg), ctypes.c_size_t(len(msg)))
+
+    def challenge_bytes(self, label, n):
+        out = _buf(max(1, n))
+        lib().orc_transcript_challenge_bytes(self.buf, label, ctypes.c_size_t(len(label)), out, ctypes.c_size_t(n))
+        return out.raw[:n]
+
+    def commit_point(self, curve, label, p):
+        assert lib().orc_transcript_commit_point(curve, self.buf, label, bytes(p)) == 0
+
+    def challenge_scalar(self, curve, label):
+        out = _buf(FR_BYTES)
+        assert lib().orc_transcript_challenge_scalar(curve, self.buf, label, out) == 0
+        return out.raw
+
+
+def ipp_create(curve, tr, Q, Gf, Hf, G, H, a, b, n):
+    lg = max(0, n.bit_length() - 1)
+    L, R = _buf(max(1, lg) * pt_bytes(curve)), _buf(max(1, lg) * pt_bytes(curve))
+    ao, bo = _buf(FR_BYTES), _buf(FR_BYTES)
+    rc = lib().orc_ipp_create(ctypes.c_int(curve), tr.buf, bytes(Q), bytes(Gf), bytes(Hf), bytes(G), bytes(H), bytes(a), bytes(b),
+                              ctypes.c_size_t(n), L, R, ao, bo)
+    if rc:
+        return rc, None
+    pb = pt_bytes(curve)
+    return 0, (L.raw[: lg * pb], R.raw[: lg * pb], ao.raw, bo.raw)
+
+
+def ipp_verify(curve, tr, n, Gf, Hf, P, Q, G, H, a, b, L, R, lg_n):
+    return lib().orc_ipp_verify(ctypes.c_int(curve), tr.buf, ctypes.c_size_t(n), bytes(Gf), bytes(Hf), bytes(P), bytes(Q),
+                                bytes(G), bytes(H), bytes(a), bytes(b), bytes(L), bytes(R), ctypes.c_size_t(lg_n))
+
+
+def ipp_verification_scalars(curve, tr, L, R, lg_n, n):
+    us, uis, s = _buf(max(1, lg_n) * 32), _buf(max(1, lg_n) * 32), _buf(max(1, n) * 32)
+    rc = lib().orc_ipp_verification_scalars(ctypes.c_int(curve), tr.buf, bytes(L), bytes(R), ctypes.c_size_t(lg_n),
+                                            ctypes.c_size_t(n), us, uis, s)
+    if rc:
+        return rc, None
+    return 0, (us.raw[: lg_n * 32], uis.raw[: lg_n * 32], s.raw[: n * 32])

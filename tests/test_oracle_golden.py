@@ -1,0 +1,146 @@
+"""CPU: the C oracle (oracle/liboracle.so) against the committed golden vectors (tests/golden/*.json,
+written by oracle/gen_golden.py from Python-int arithmetic) and the public KATs."""
+import pytest
+
+import _oracle as O
+
+CURVES = ["bls12_381", "bn254"]
+
+
+def hx(s):
+    return bytes.fromhex(s)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_curve_constants(golden, name):
+    g = golden("curves")[name]
+    cid = O.CURVE_IDS[name]
+    assert g["curve_id"] == cid
+    G = O.generator(cid)
+    assert G == hx(g["G"])
+    assert O.on_curve(cid, G)
+    assert O.g1_add(cid, G, G) == hx(g["G2"])
+    assert O.g1_add(cid, hx(g["G2"]), G) == hx(g["G3"])
+    rm1 = (int(g["r"], 16) - 1).to_bytes(32, "little")
+    assert O.g1_mul(cid, rm1, G) == hx(g["G_rm1"])
+    assert O.g1_add(cid, hx(g["G_rm1"]), G) == bytes(len(G))          # r*G = O
+    assert O.g1_to_amcl(cid, G) == hx(g["G_amcl"])
+    assert O.g1_to_amcl(cid, bytes(len(G))) == hx(g["identity_amcl"])
+    if name == "bls12_381":   # published 2G
+        x2 = int("0572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e", 16)
+        assert O.g1_add(cid, G, G)[:48] == x2.to_bytes(48, "little")
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_field_ops(golden, name):
+    cid = O.CURVE_IDS[name]
+    for which, key in ((0, "fp"), (1, "fr")):
+        for c in golden("field")[name][key]:
+            a, b = hx(c["a"]), hx(c["b"])
+            assert O.field_op(cid, which, 0, a, b) == hx(c["add"])
+            assert O.field_op(cid, which, 1, a, b) == hx(c["sub"])
+            assert O.field_op(cid, which, 2, a, b) == hx(c["mul"])
+            assert O.field_op(cid, which, 3, a, b) == hx(c["inv_a"])
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_g1_ops(golden, name):
+    cid = O.CURVE_IDS[name]
+    g = golden("g1")[name]
+    for c in g["add"]:
+        assert O.g1_add(cid, hx(c["p"]), hx(c["q"])) == hx(c["sum"])
+    for c in g["mul"]:
+        assert O.g1_mul(cid, hx(c["k"]), hx(c["p"])) == hx(c["kp"])
+    for c in g["binary_scalar_mul"]:
+        assert O.binary_scalar_mul(cid, hx(c["p"]), hx(c["q"]), hx(c["k1"]), hx(c["k2"])) == hx(c["out"])
+
+
+@pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("algo", [O.NAIVE, O.STRAUSS, O.PIPPENGER])
+def test_msm_golden(golden, name, algo):
+    cid = O.CURVE_IDS[name]
+    for c in golden("msm")[name]:
+        pts = b"".join(hx(p) for p in c["points"])
+        sc = b"".join(hx(s) for s in c["scalars"])
+        assert O.msm(cid, pts, sc, c["n"], algo=algo) == hx(c["out"]), c["name"]
+    c = golden("msm")[name][5]
+    pts = b"".join(hx(p) for p in c["points"])
+    sc = b"".join(hx(s) for s in c["scalars"])
+    assert O.msm(cid, pts, sc, c["n"], algo=O.PIPPENGER, nthreads=4) == hx(c["out"])
+
+
+def test_merlin_golden(golden):
+    for c in golden("merlin"):
+        t = O.Transcript(hx(c["label"]))
+        got = []
+        for op in c["ops"]:
+            if op[0] == "append":
+                t.append_message(hx(op[1]), hx(op[2]))
+            else:
+                got.append(t.challenge_bytes(hx(op[1]), op[2]).hex())
+        assert got == c["challenges"], c["name"]
+    assert golden("merlin")[0]["challenges"][0] == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ipp_golden(golden, name):
+    cid = O.CURVE_IDS[name]
+    for c in golden("ipp")[name]:
+        n = c["n"]
+        cat = lambda k: b"".join(hx(x) for x in c[k])
+        tr = O.Transcript(b"innerproduct")
+        rc, out = O.ipp_create(cid, tr, hx(c["Q"]), cat("G_factors"), cat("H_factors"), cat("G"), cat("H"), cat("a"), cat("b"), n)
+        assert rc == 0
+        L, R, a0, b0 = out
+        assert L == cat("L") and R == cat("R"), c["name"]
+        assert a0 == hx(c["a_out"]) and b0 == hx(c["b_out"])
+        assert tr.challenge_bytes(b"after", 32).hex() == c["transcript_after"]
+        lg = len(c["L"])
+        for i, lam in enumerate(c["L_amcl"]):
+            assert O.g1_to_amcl(cid, hx(c["L"][i])).hex() == lam
+        ok = O.ipp_verify(cid, O.Transcript(b"innerproduct"), n, cat("G_factors"), cat("H_factors"), hx(c["P"]), hx(c["Q"]),
+                          cat("G"), cat("H"), a0, b0, L, R, lg)
+        assert ok == 0
+        bad_a = ((int.from_bytes(a0, "little") + 1) % int(golden("curves")[name]["r"], 16)).to_bytes(32, "little")
+        assert O.ipp_verify(cid, O.Transcript(b"innerproduct"), n, cat("G_factors"), cat("H_factors"), hx(c["P"]), hx(c["Q"]),
+                            cat("G"), cat("H"), bad_a, b0, L, R, lg) == 3
+        # verification_scalars error exits (src/ipp.rs:269-276)
+        assert O.ipp_verify(cid, O.Transcript(b"innerproduct"), 2 * n, cat("G_factors"), cat("H_factors"), hx(c["P"]), hx(c["Q"]),
+                            cat("G"), cat("H"), a0, b0, L, R, lg) == 3
+
+
+def test_ipp_create_rejects_non_power_of_two():
+    cid = 0
+    G = O.generator(cid)
+    z = bytes(32)
+    rc, _ = O.ipp_create(cid, O.Transcript(b"innerproduct"), G, z * 3, z * 3, G * 3, G * 3, z * 3, z * 3, 3)
+    assert rc == 2
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_fixed_base_and_linearity(golden, name):
+    """MSM(s, k.G) == (sum s_i k_i) G -- the size-independent property the full-size GPU tests use."""
+    cid = O.CURVE_IDS[name]
+    r = int(golden("curves")[name]["r"], 16)
+    n = 200
+    ks = O.random_scalars(cid, 11, n)
+    ss = O.random_scalars(cid, 12, n)
+    pts = O.fixed_base_batch(cid, ks, n, nthreads=3)
+    G = O.generator(cid)
+    pb = O.pt_bytes(cid)
+    for i in (0, 1, n - 1):
+        assert pts[i * pb:(i + 1) * pb] == O.g1_mul(cid, ks[i * 32:(i + 1) * 32], G)
+    dot = O.fr_inner(cid, ks, ss, n)
+    exp = sum(int.from_bytes(ks[i * 32:(i + 1) * 32], "little") * int.from_bytes(ss[i * 32:(i + 1) * 32], "little") for i in range(n)) % r
+    assert dot == exp.to_bytes(32, "little")
+    assert O.msm(cid, pts, ss, n, algo=O.PIPPENGER, nthreads=2) == O.g1_mul(cid, dot, G)
+
+
+def test_random_scalars_match_pyref(golden):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref
+    for c in (pyref.BLS12_381, pyref.BN254):
+        rng = pyref.SplitMix64(77)
+        exp = b"".join(c.fr_to_le(rng.scalar(c)) for _ in range(20))
+        assert O.random_scalars(c.curve_id, 77, 20) == exp
