@@ -1,0 +1,328 @@
+"""bulletproofs-amcl_amd -- MI355X-native MSM / inner-product-argument engine (host-side Python mirror).
+
+The directory name carries a hyphen, so the package is loaded under the import name
+``bulletproofs_amcl_amd`` by ``__graft_entry__.load_package()``.
+
+This module is plumbing above the C ABI (include/bpmsm.h, libbpmsm.so): thin ctypes wrappers whose names
+follow the reference's types -- ``G1Vector`` / ``FieldElementVector`` (amcl_wrapper types used throughout
+/root/reference src/ipp.rs) -- so that the parity tests read like the reference's own tests.  It contains no
+arithmetic and no CPU fallback: every compute call goes to the HIP library and raises ``DeviceError`` when there
+is no GPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbpmsm.so")
+
+BP_OK, BP_ERR_LENGTH, BP_ERR_ARG, BP_ERR_VERIFY, BP_ERR_DEVICE = 0, 1, 2, 3, 4
+BLS12_381, BN254 = 0, 1
+FMT_LE, FMT_AMCL = 0, 1
+CURVE_IDS = {"bls12_381": BLS12_381, "bn254": BN254}
+
+
+class BpError(RuntimeError):
+    code = -1
+
+
+class ValueError_(BpError):
+    """amcl_wrapper::errors::ValueError (length mismatch)."""
+    code = BP_ERR_LENGTH
+
+
+class ArgError(BpError):
+    """assert!/assert_eq! panics of the reference (src/ipp.rs:48-55)."""
+    code = BP_ERR_ARG
+
+
+class VerificationError(BpError):
+    """R1CSError::VerificationError (src/errors.rs:7-28)."""
+    code = BP_ERR_VERIFY
+
+
+class DeviceError(BpError):
+    code = BP_ERR_DEVICE
+
+
+_ERRS = {BP_ERR_LENGTH: ValueError_, BP_ERR_ARG: ArgError, BP_ERR_VERIFY: VerificationError, BP_ERR_DEVICE: DeviceError}
+
+
+def _check(rc, what=""):
+    if rc != BP_OK:
+        raise _ERRS.get(rc, BpError)("%s failed with status %d" % (what, rc))
+
+
+class CurveInfo(ctypes.Structure):
+    _fields_ = [("curve_id", ctypes.c_int), ("fp_bytes", ctypes.c_int), ("fr_bytes", ctypes.c_int), ("modbytes", ctypes.c_int),
+                ("fr_bits", ctypes.c_int), ("p_le", ctypes.c_uint8 * 48), ("r_le", ctypes.c_uint8 * 32), ("gen_le", ctypes.c_uint8 * 96)]
+
+
+# every symbol include/bpmsm.h declares: name -> (restype, argtypes)
+_P, _SZ, _I, _U8P = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p
+_PP = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = {
+    "bp_version": (ctypes.c_char_p, []),
+    "bp_curve_params": (_I, [_I, ctypes.POINTER(CurveInfo)]),
+    "bp_device_count": (_I, []),
+    "bp_ctx_create": (_I, [_I, _I, _PP]),
+    "bp_ctx_destroy": (_I, [_P]),
+    "bp_ctx_set_stream": (_I, [_P, _P]),
+    "bp_ctx_synchronize": (_I, [_P]),
+    "bp_ctx_set_window_bits": (_I, [_P, _I]),
+    "bp_ctx_enable_timing": (_I, [_P, _I]),
+    "bp_g1vec_upload": (_I, [_P, _U8P, _SZ, _I, _PP]),
+    "bp_g1vec_alloc": (_I, [_P, _SZ, _PP]),
+    "bp_g1vec_download": (_I, [_P, _P, _SZ, _SZ, _I, _U8P]),
+    "bp_g1vec_free": (_I, [_P]),
+    "bp_g1vec_len": (_SZ, [_P]),
+    "bp_g1vec_device_ptr": (_P, [_P]),
+    "bp_g1vec_wrap_device": (_I, [_P, _P, _SZ, _PP]),
+    "bp_g1vec_fixed_base_mul": (_I, [_P, _P, _PP]),
+    "bp_g1vec_scalar_mul": (_I, [_P, _P, _P, _PP]),
+    "bp_frvec_upload": (_I, [_P, _U8P, _SZ, _PP]),
+    "bp_frvec_alloc": (_I, [_P, _SZ, _PP]),
+    "bp_frvec_download": (_I, [_P, _P, _SZ, _SZ, _U8P]),
+    "bp_frvec_free": (_I, [_P]),
+    "bp_frvec_len": (_SZ, [_P]),
+    "bp_frvec_device_ptr": (_P, [_P]),
+    "bp_frvec_wrap_device": (_I, [_P, _P, _SZ, _PP]),
+    "bp_msm_g1": (_I, [_P, _P, _P, _U8P]),
+    "bp_msm_g1_range": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _U8P]),
+    "bp_msm_window_records": (_SZ, [_P, _SZ]),
+    "bp_msm_record_bytes": (_SZ, [_I]),
+    "bp_msm_g1_windows": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _P]),
+    "bp_msm_g1_finish": (_I, [_P, _P, _SZ, _SZ, _U8P]),
+    "bp_msm_last_timing": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
+}
+
+_lib = None
+
+
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.7.  Two HIP runtimes in one process cannot both own the GPU, so
+    when torch is installed its copy is loaded first and libbpmsm.so (NEEDED libamdhip64.so.7) binds to it; the
+    bench and the sharded path then share streams and device memory with torch / RCCL."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+def lib():
+    """Load libbpmsm.so.  Fails loudly if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError("libbpmsm.so is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        _preload_torch_hip_runtime()
+        L = ctypes.CDLL(_SO)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def curve_info(curve):
+    info = CurveInfo()
+    _check(lib().bp_curve_params(curve, ctypes.byref(info)), "bp_curve_params")
+    return info
+
+
+def device_count():
+    return lib().bp_device_count()
+
+
+class Context:
+    """One per host thread; owns a HIP stream and the MSM workspace (bp_ctx)."""
+
+    def __init__(self, curve=BLS12_381, device=0):
+        self.curve = curve
+        self.h = ctypes.c_void_p()
+        _check(lib().bp_ctx_create(curve, device, ctypes.byref(self.h)), "bp_ctx_create")
+        info = curve_info(curve)
+        self.fp_bytes, self.fr_bytes, self.modbytes = info.fp_bytes, info.fr_bytes, info.modbytes
+        self.point_bytes = 2 * info.fp_bytes
+        self.r = int.from_bytes(bytes(info.r_le), "little")
+
+    def close(self):
+        if self.h:
+            lib().bp_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().bp_ctx_set_stream(self.h, ctypes.c_void_p(hip_stream)), "bp_ctx_set_stream")
+
+    def synchronize(self):
+        _check(lib().bp_ctx_synchronize(self.h), "bp_ctx_synchronize")
+
+    def set_window_bits(self, c):
+        _check(lib().bp_ctx_set_window_bits(self.h, c), "bp_ctx_set_window_bits")
+
+    def enable_timing(self, on=True):
+        _check(lib().bp_ctx_enable_timing(self.h, 1 if on else 0), "bp_ctx_enable_timing")
+
+    def last_timing(self):
+        buf = (ctypes.c_float * 8)()
+        k = lib().bp_msm_last_timing(self.h, buf, 8)
+        return [buf[i] for i in range(k)]
+
+
+class G1Vector:
+    """amcl_wrapper::group_elem_g1::G1Vector, resident in HBM."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def from_bytes(cls, ctx, data, n, fmt=FMT_LE):
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_upload(ctx.h, bytes(data), n, fmt, ctypes.byref(h)), "bp_g1vec_upload")
+        return cls(ctx, h)
+
+    @classmethod
+    def new(cls, ctx, n):
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_alloc(ctx.h, n, ctypes.byref(h)), "bp_g1vec_alloc")
+        return cls(ctx, h)
+
+    @classmethod
+    def wrap_device(cls, ctx, device_ptr, n):
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_wrap_device(ctx.h, ctypes.c_void_p(device_ptr), n, ctypes.byref(h)), "bp_g1vec_wrap_device")
+        return cls(ctx, h)
+
+    @classmethod
+    def fixed_base(cls, ctx, scalars):
+        """[k_i * G]"""
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_fixed_base_mul(ctx.h, scalars.h, ctypes.byref(h)), "bp_g1vec_fixed_base_mul")
+        return cls(ctx, h)
+
+    def scaled_by(self, scalars):
+        """[k_i * P_i]"""
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_scalar_mul(self.ctx.h, self.h, scalars.h, ctypes.byref(h)), "bp_g1vec_scalar_mul")
+        return G1Vector(self.ctx, h)
+
+    def __len__(self):
+        return lib().bp_g1vec_len(self.h)
+
+    def device_ptr(self):
+        return lib().bp_g1vec_device_ptr(self.h)
+
+    def to_bytes(self, offset=0, n=None, fmt=FMT_LE):
+        n = len(self) - offset if n is None else n
+        per = self.ctx.point_bytes if fmt == FMT_LE else self.ctx.point_bytes + 1
+        buf = ctypes.create_string_buffer(max(1, n * per))
+        _check(lib().bp_g1vec_download(self.ctx.h, self.h, offset, n, fmt, buf), "bp_g1vec_download")
+        return buf.raw[: n * per]
+
+    # G1Vector::multi_scalar_mul_var_time / inner_product_var_time_with_ref_vecs / inner_product_const_time
+    def multi_scalar_mul_var_time(self, scalars):
+        out = ctypes.create_string_buffer(self.ctx.point_bytes)
+        _check(lib().bp_msm_g1(self.ctx.h, self.h, scalars.h, out), "bp_msm_g1")
+        return out.raw
+
+    inner_product_var_time = multi_scalar_mul_var_time
+    inner_product_const_time = multi_scalar_mul_var_time
+
+    def msm_range(self, poff, scalars, soff, n):
+        out = ctypes.create_string_buffer(self.ctx.point_bytes)
+        _check(lib().bp_msm_g1_range(self.ctx.h, self.h, poff, scalars.h, soff, n, out), "bp_msm_g1_range")
+        return out.raw
+
+    def free(self):
+        if self.h:
+            lib().bp_g1vec_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FieldElementVector:
+    """amcl_wrapper::field_elem::FieldElementVector, resident in HBM (32-byte canonical LE scalars)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def from_bytes(cls, ctx, data, n):
+        h = ctypes.c_void_p()
+        _check(lib().bp_frvec_upload(ctx.h, bytes(data), n, ctypes.byref(h)), "bp_frvec_upload")
+        return cls(ctx, h)
+
+    @classmethod
+    def from_ints(cls, ctx, values):
+        return cls.from_bytes(ctx, b"".join((v % ctx.r).to_bytes(32, "little") for v in values), len(values))
+
+    @classmethod
+    def new(cls, ctx, n):
+        h = ctypes.c_void_p()
+        _check(lib().bp_frvec_alloc(ctx.h, n, ctypes.byref(h)), "bp_frvec_alloc")
+        return cls(ctx, h)
+
+    @classmethod
+    def wrap_device(cls, ctx, device_ptr, n):
+        h = ctypes.c_void_p()
+        _check(lib().bp_frvec_wrap_device(ctx.h, ctypes.c_void_p(device_ptr), n, ctypes.byref(h)), "bp_frvec_wrap_device")
+        return cls(ctx, h)
+
+    def __len__(self):
+        return lib().bp_frvec_len(self.h)
+
+    def device_ptr(self):
+        return lib().bp_frvec_device_ptr(self.h)
+
+    def to_bytes(self, offset=0, n=None):
+        n = len(self) - offset if n is None else n
+        buf = ctypes.create_string_buffer(max(1, n * 32))
+        _check(lib().bp_frvec_download(self.ctx.h, self.h, offset, n, buf), "bp_frvec_download")
+        return buf.raw[: n * 32]
+
+    def free(self):
+        if self.h:
+            lib().bp_frvec_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_windows(ctx, points, poff, scalars, soff, n, device_out_ptr):
+    """Stage 1 of the sharded MSM: W window records into caller-owned HBM (see include/bpmsm.h)."""
+    _check(lib().bp_msm_g1_windows(ctx.h, points.h, poff, scalars.h, soff, n, ctypes.c_void_p(device_out_ptr)), "bp_msm_g1_windows")
+
+
+def msm_finish(ctx, device_records_ptr, sets, n_per_set):
+    out = ctypes.create_string_buffer(ctx.point_bytes)
+    _check(lib().bp_msm_g1_finish(ctx.h, ctypes.c_void_p(device_records_ptr), sets, n_per_set, out), "bp_msm_g1_finish")
+    return out.raw
+
+
+def msm_window_records(ctx, n):
+    return lib().bp_msm_window_records(ctx.h, n)
+
+
+def msm_record_bytes(curve):
+    return lib().bp_msm_record_bytes(curve)

@@ -1,0 +1,628 @@
+// bp_capi.hip -- implementation of the C ABI in include/bpmsm.h (libbpmsm.so).
+// Host orchestration of the gfx950 kernels in bp_kernels.cuh; no CPU fallback for any compute entry point.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/bpmsm.h"
+#include "bp_kernels.cuh"
+
+using namespace bp;
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            if (getenv("BP_VERBOSE")) fprintf(stderr, "[bpmsm] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return BP_ERR_DEVICE;                                                                            \
+        }                                                                                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ handles
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return BP_OK;
+        if (p) { if (hipFree(p) != hipSuccess) return BP_ERR_DEVICE; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return BP_ERR_DEVICE; }
+        cap = want;
+        return BP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct bp_ctx {
+    int curve = 0;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int c_override = 0;
+    bool timing = false;
+    // MSM workspace
+    DevBuf count, cursor, block_sums, idx, code, ntasks, task_off, order, t_start, t_len, tsum, heavy, meta, partial, window_sum, scratch;
+    void* host_pinned = nullptr;
+    size_t host_pinned_cap = 0;
+    hipEvent_t ev[8] = {};
+    bool ev_ready = false;
+    float last_ms[8] = {};
+    int last_ms_n = 0;
+};
+
+struct bp_g1vec {
+    bp_ctx* ctx;
+    void* d;
+    size_t n;
+    bool owned;
+};
+struct bp_frvec {
+    bp_ctx* ctx;
+    void* d;
+    size_t n;
+    bool owned;
+};
+
+static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
+static inline bool curve_ok(int curve) { return curve == BP_CURVE_BLS12_381 || curve == BP_CURVE_BN254; }
+
+static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->host_pinned_cap) return BP_OK;
+    if (ctx->host_pinned) { HIPCHK(hipHostFree(ctx->host_pinned)); ctx->host_pinned = nullptr; ctx->host_pinned_cap = 0; }
+    HIPCHK(hipHostMalloc(&ctx->host_pinned, bytes + 4096, hipHostMallocDefault));
+    ctx->host_pinned_cap = bytes + 4096;
+    return BP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+struct MsmGeom {
+    int c;           // target window width
+    WinTab tab;      // W windows of nearly equal width covering fr_bits + 1 bits
+    uint32_t m;      // buckets per reduce thread
+    uint32_t bpw;    // reduce blocks per window (max over windows)
+};
+
+static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
+    int c = c_override;
+    if (c <= 0) {
+        int lg = 0;
+        while (((size_t)1 << (lg + 1)) <= n) lg++;
+        c = lg - 4;
+    }
+    if (c < 2) c = 2;
+    if (c > 16) c = 16;
+    g.c = c;
+    int cover = fr_bits + 1;
+    int W = (cover + c - 1) / c;
+    int base = cover / W, extra = cover % W;     // `extra` windows of base+1 bits, the rest base bits (all <= c)
+    WinTab& t = g.tab;
+    memset(&t, 0, sizeof t);
+    t.W = W;
+    uint32_t bias[8] = {0};
+    int off = 0;
+    uint32_t nb = 0, maxB = 0;
+    for (int w = 0; w < W; w++) {
+        int cw = base + (w < extra ? 1 : 0);
+        t.cw[w] = (uint8_t)cw;
+        t.off[w] = (uint16_t)off;
+        t.boff[w] = nb;
+        uint32_t B = 1u << (cw - 1);
+        nb += B;
+        if (B > maxB) maxB = B;
+        // bias += (2^(cw-1) - 1) << off
+        uint64_t half1 = (uint64_t)B - 1;
+        int word = off >> 5, sh = off & 31;
+        unsigned __int128 add = (unsigned __int128)half1 << sh;
+        uint64_t carry = 0;
+        for (int k = word; k < 8; k++) {
+            uint64_t v = (uint64_t)bias[k] + (uint64_t)(add & 0xffffffffu) + carry;
+            bias[k] = (uint32_t)v;
+            carry = v >> 32;
+            add >>= 32;
+            if (!add && !carry) break;
+        }
+        off += cw;
+    }
+    t.boff[W] = nb;
+    t.nbuckets = nb;
+    memcpy(t.bias.w, bias, sizeof bias);
+    uint32_t m = 1;
+    while (m < 8 && nb / m > 65536) m <<= 1;
+    g.m = m;
+    uint32_t T = (maxB + m - 1) / m;
+    g.bpw = (T + kBlock - 1) / kBlock;
+}
+
+// ------------------------------------------------------------------------------------------------ per-curve code
+template <class C>
+struct Impl {
+    using Fp = typename C::Fp;
+    static constexpr size_t kPointBytes = sizeof(AffPacked<C>);
+    static constexpr size_t kXyzzBytes = sizeof(XyzzPacked<C>);
+
+    static int ensure_events(bp_ctx* ctx) {
+        if (ctx->ev_ready) return BP_OK;
+        for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+        ctx->ev_ready = true;
+        return BP_OK;
+    }
+
+    // Device stage: window sums of  sum_i s_i P_i  into ctx->window_sum (W records).
+    static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g) {
+        msm_geom(g, C::Fr::BITS, n, ctx->c_override);
+        const WinTab& tab = g.tab;
+        const int W = tab.W;
+        if (n >= ((size_t)1 << 31)) return BP_ERR_ARG;                      // the sign lives in bit 31 of an index
+        if ((uint64_t)W * n >= ((uint64_t)1 << 32)) return BP_ERR_ARG;      // 32-bit slot offsets
+        hipStream_t st = ctx->stream;
+        size_t nb = tab.nbuckets;
+        size_t scan_blocks = (nb + kScanPerBlock - 1) / kScanPerBlock;
+        // task length: power of two >= 128 and >= 2x the mean bucket size
+        uint32_t L = 128, lshift = 0;
+        while ((uint64_t)L * nb < 2 * (uint64_t)W * n && L < (1u << 20)) { L <<= 1; lshift++; }
+        size_t max_split = ((size_t)W * n) / L + 1;                         // tasks beyond one per bucket
+        size_t max_tasks = nb + max_split;
+        size_t max_heavy = (nb < max_split ? nb : max_split) + 1;
+        int rc;
+        if ((rc = ctx->count.reserve(nb * 4))) return rc;
+        if ((rc = ctx->cursor.reserve(nb * 4))) return rc;
+        if ((rc = ctx->ntasks.reserve(nb * 4))) return rc;
+        if ((rc = ctx->task_off.reserve(nb * 4))) return rc;
+        if ((rc = ctx->block_sums.reserve(scan_blocks * 4 + 16))) return rc;
+        if ((rc = ctx->idx.reserve((size_t)W * n * 4))) return rc;
+        if ((rc = ctx->code.reserve((size_t)W * n * 2))) return rc;
+        if ((rc = ctx->order.reserve(max_tasks * 4))) return rc;
+        if ((rc = ctx->t_start.reserve(max_tasks * 4))) return rc;
+        if ((rc = ctx->t_len.reserve(max_tasks * 4))) return rc;
+        if ((rc = ctx->tsum.reserve(max_tasks * kXyzzBytes))) return rc;
+        if ((rc = ctx->heavy.reserve(max_heavy * 4))) return rc;
+        if ((rc = ctx->meta.reserve((kTaskBins + 2) * 4))) return rc;
+        if ((rc = ctx->partial.reserve((size_t)W * g.bpw * kXyzzBytes))) return rc;
+        if ((rc = ctx->window_sum.reserve((size_t)W * kXyzzBytes))) return rc;
+        uint32_t* count = (uint32_t*)ctx->count.p;       // histogram, then bucket starts
+        uint32_t* cursor = (uint32_t*)ctx->cursor.p;     // scatter cursors, then bucket ends
+        uint32_t* ntasks = (uint32_t*)ctx->ntasks.p;
+        uint32_t* task_off = (uint32_t*)ctx->task_off.p;
+        uint32_t* bsum = (uint32_t*)ctx->block_sums.p;
+        uint32_t* idx = (uint32_t*)ctx->idx.p;
+        uint16_t* code = (uint16_t*)ctx->code.p;
+        uint32_t* order = (uint32_t*)ctx->order.p;
+        uint32_t* t_start = (uint32_t*)ctx->t_start.p;
+        uint32_t* t_len = (uint32_t*)ctx->t_len.p;
+        uint32_t* heavy = (uint32_t*)ctx->heavy.p;
+        uint32_t* bins = (uint32_t*)ctx->meta.p;          // [kTaskBins] bin counts -> bin cursors
+        uint32_t* total_tasks = bins + kTaskBins;
+        uint32_t* nheavy = bins + kTaskBins + 1;
+        auto* tsum = (XyzzPacked<C>*)ctx->tsum.p;
+        auto* partial = (XyzzPacked<C>*)ctx->partial.p;
+        auto* wsum = (XyzzPacked<C>*)ctx->window_sum.p;
+
+        bool tm = ctx->timing;
+        if (tm) { if ((rc = ensure_events(ctx))) return rc; HIPCHK(hipEventRecord(ctx->ev[0], st)); }
+        HIPCHK(hipMemsetAsync(count, 0, nb * 4, st));
+        HIPCHK(hipMemsetAsync(bins, 0, (kTaskBins + 2) * 4, st));
+        unsigned sgrid = (unsigned)((n + kBlock - 1) / kBlock);
+        if (sgrid > 256 * 16) sgrid = 256 * 16;
+        hipLaunchKernelGGL(k_digits_count, dim3(sgrid), dim3(kBlock), 0, st, sc, n, tab, code, count);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
+        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, count, nb, bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, bsum, scan_blocks);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, count, nb, bsum, count, cursor);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
+        unsigned tgrid = (unsigned)((n + kBlock - 1) / kBlock);
+        if (tgrid > 1024) tgrid = 1024;
+        hipLaunchKernelGGL(k_digits_scatter, dim3(tgrid, W), dim3(kBlock), 0, st, code, n, tab, cursor, idx);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[3], st));
+        // count[] = bucket starts, cursor[] = bucket ends.  Tasks:
+        unsigned bgrid = (unsigned)((nb + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, ntasks, bins);
+        hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, st, bins, total_tasks);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, bsum, scan_blocks);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum, task_off, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len, heavy, nheavy);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));
+        hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((max_tasks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pts, idx, order, t_start, t_len,
+                           total_tasks, tsum);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
+        hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)max_heavy), dim3(64), 0, st, heavy, nheavy, task_off, ntasks, tsum);
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(g.bpw, W), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
+        hipLaunchKernelGGL(k_window_sums<C>, dim3(W), dim3(kBlock), 0, st, partial, g.bpw, wsum);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
+        HIPCHK(hipGetLastError());
+        return BP_OK;
+    }
+
+    static void collect_timing(bp_ctx* ctx) {
+        ctx->last_ms_n = 0;
+        if (!ctx->timing || !ctx->ev_ready) return;
+        if (hipEventSynchronize(ctx->ev[6]) != hipSuccess) return;
+        float t;
+        if (hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->last_ms[0] = t;
+        for (int i = 0; i < 6; i++)
+            if (hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]) == hipSuccess) ctx->last_ms[1 + i] = t;
+        ctx->last_ms_n = 7;
+    }
+
+    // Host stage: fold `sets` sets of W window sums (host memory, packed XYZZ) into one affine point.
+    //   result = sum_w 2^(off_w) * (sum_s rec[s][w])     (Horner over the windows, cw[w] doublings per step)
+    static void fold_windows(const XyzzPacked<C>* rec, size_t sets, const MsmGeom& g, Aff<C>& out) {
+        const int W = g.tab.W;
+        Xyzz<C> acc = xyzz_inf<C>();
+        for (int w = W - 1; w >= 0; w--) {
+            if (!xyzz_is_inf(acc)) for (int i = 0; i < g.tab.cw[w]; i++) acc = xyzz_dbl(acc);
+            for (size_t s = 0; s < sets; s++) acc = xyzz_add(acc, xyzz_unpack(rec[s * W + w]));
+        }
+        out = xyzz_to_aff<C>(acc);
+    }
+
+    static void aff_to_le(const Aff<C>& a, uint8_t* out) {
+        uint32_t w[Fp::NW];
+        fe_pack_words<Fp>(w, fe_from_mont<Fp>(a.x));
+        memcpy(out, w, 4 * Fp::NW);
+        fe_pack_words<Fp>(w, fe_from_mont<Fp>(a.y));
+        memcpy(out + 4 * Fp::NW, w, 4 * Fp::NW);
+    }
+
+    static int msm(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, uint8_t* out_le) {
+        if (n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); ctx->last_ms_n = 0; return BP_OK; }
+        MsmGeom g;
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
+        if (rc) return rc;
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        collect_timing(ctx);
+        Aff<C> r;
+        fold_windows((const XyzzPacked<C>*)ctx->host_pinned, 1, g, r);
+        aff_to_le(r, out_le);
+        return BP_OK;
+    }
+
+    static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
+        MsmGeom g;
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(device_out, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return BP_OK;
+    }
+
+    static int msm_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
+        MsmGeom g;
+        msm_geom(g, C::Fr::BITS, n_per_set, ctx->c_override);
+        size_t bytes = sets * (size_t)g.tab.W * kXyzzBytes;
+        int rc;
+        if ((rc = host_pinned_reserve(ctx, bytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, device_records, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        collect_timing(ctx);
+        Aff<C> r;
+        fold_windows((const XyzzPacked<C>*)ctx->host_pinned, sets, g, r);
+        aff_to_le(r, out_le);
+        return BP_OK;
+    }
+
+    static int upload_points(bp_ctx* ctx, const uint8_t* le, size_t n, void* d_out) {
+        size_t bytes = n * 2 * 4 * Fp::NW;
+        int rc;
+        if ((rc = ctx->scratch.reserve(bytes ? bytes : 16))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->scratch.p, le, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const uint32_t*)ctx->scratch.p, n, (AffPacked<C>*)d_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // `le` is a borrowed host buffer
+        return BP_OK;
+    }
+
+    static int download_points(bp_ctx* ctx, const void* d_in, size_t offset, size_t n, uint8_t* le) {
+        size_t bytes = n * 2 * 4 * Fp::NW;
+        int rc;
+        if ((rc = ctx->scratch.reserve(bytes ? bytes : 16))) return rc;
+        hipLaunchKernelGGL(k_points_from_resident<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const AffPacked<C>*)d_in + offset, n, (uint32_t*)ctx->scratch.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(le, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return BP_OK;
+    }
+
+    static int scalar_mul(bp_ctx* ctx, const void* base, const void* k, size_t n, void* out) {
+        hipLaunchKernelGGL(k_scalar_mul<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const AffPacked<C>*)base, (const ScalarWords*)k, n, (AffPacked<C>*)out);
+        HIPCHK(hipGetLastError());
+        return BP_OK;
+    }
+};
+
+#define DISPATCH(ctx_, expr)                                              \
+    do {                                                                  \
+        if ((ctx_)->curve == BP_CURVE_BLS12_381) { using I = Impl<Bls381>; return expr; } \
+        else { using I = Impl<Bn254>; return expr; }                      \
+    } while (0)
+
+static int set_device(const bp_ctx* ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return BP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* bp_version(void) { return "bpmsm 0.1 (gfx950; unsaturated 30-bit limbs; Pippenger/XYZZ)"; }
+
+int bp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bp_curve_params(int curve_id, bp_curve_info* out) {
+    if (!out || !curve_ok(curve_id)) return BP_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    out->curve_id = curve_id;
+    out->fr_bytes = 32;
+    if (curve_id == BP_CURVE_BLS12_381) {
+        out->fp_bytes = 48; out->modbytes = Bls381::MODBYTES; out->fr_bits = Bls381Fr::BITS;
+        memcpy(out->p_le, Bls381FpW::MODW, 48); memcpy(out->r_le, Bls381FrW::MODW, 32);
+        memcpy(out->gen_le, Bls381::GX, 48); memcpy(out->gen_le + 48, Bls381::GY, 48);
+    } else {
+        out->fp_bytes = 32; out->modbytes = Bn254::MODBYTES; out->fr_bits = Bn254Fr::BITS;
+        memcpy(out->p_le, Bn254FpW::MODW, 32); memcpy(out->r_le, Bn254FrW::MODW, 32);
+        memcpy(out->gen_le, Bn254::GX, 32); memcpy(out->gen_le + 32, Bn254::GY, 32);
+    }
+    return BP_OK;
+}
+
+int bp_ctx_create(int curve_id, int device_ordinal, bp_ctx** out) {
+    if (!out || !curve_ok(curve_id)) return BP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BP_ERR_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= ndev) return BP_ERR_ARG;
+    HIPCHK(hipSetDevice(device_ordinal));
+    bp_ctx* ctx = new (std::nothrow) bp_ctx();
+    if (!ctx) return BP_ERR_DEVICE;
+    ctx->curve = curve_id;
+    ctx->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BP_ERR_DEVICE; }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return BP_OK;
+}
+
+int bp_ctx_destroy(bp_ctx* ctx) {
+    if (!ctx) return BP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
+                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch}) b->release();
+    if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    if (ctx->ev_ready) for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return BP_OK;
+}
+
+int bp_ctx_set_stream(bp_ctx* ctx, void* hip_stream) {
+    if (!ctx) return BP_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return BP_OK;
+}
+
+int bp_ctx_synchronize(bp_ctx* ctx) {
+    if (!ctx) return BP_ERR_ARG;
+    int rc = set_device(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+
+int bp_ctx_set_window_bits(bp_ctx* ctx, int c) {
+    if (!ctx || c < 0 || c > 16 || c == 1) return BP_ERR_ARG;
+    ctx->c_override = c;
+    return BP_OK;
+}
+
+int bp_ctx_enable_timing(bp_ctx* ctx, int on) {
+    if (!ctx) return BP_ERR_ARG;
+    ctx->timing = on != 0;
+    return BP_OK;
+}
+
+int bp_msm_last_timing(bp_ctx* ctx, float* ms, int cap) {
+    if (!ctx || !ms) return 0;
+    int k = ctx->last_ms_n < cap ? ctx->last_ms_n : cap;
+    for (int i = 0; i < k; i++) ms[i] = ctx->last_ms[i];
+    return k;
+}
+
+// ---- G1Vector ----
+static size_t point_bytes(const bp_ctx* ctx) { return 2 * (size_t)fp_bytes_of(ctx->curve); }
+
+int bp_g1vec_alloc(bp_ctx* ctx, size_t n, bp_g1vec** out) {
+    if (!ctx || !out) return BP_ERR_ARG;
+    *out = nullptr;
+    int rc = set_device(ctx); if (rc) return rc;
+    void* d = nullptr;
+    size_t bytes = (n ? n : 1) * point_bytes(ctx);
+    HIPCHK(hipMalloc(&d, bytes));
+    if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(d); return BP_ERR_DEVICE; }
+    *out = new bp_g1vec{ctx, d, n, true};
+    return BP_OK;
+}
+
+int bp_g1vec_upload(bp_ctx* ctx, const uint8_t* points, size_t n, int fmt, bp_g1vec** out) {
+    if (!ctx || !out || (!points && n) || (fmt != BP_FMT_LE && fmt != BP_FMT_AMCL)) return BP_ERR_ARG;
+    int rc = bp_g1vec_alloc(ctx, n, out);
+    if (rc) return rc;
+    if (n == 0) return BP_OK;
+    std::vector<uint8_t> le;
+    const uint8_t* src = points;
+    int fb = fp_bytes_of(ctx->curve);
+    if (fmt == BP_FMT_AMCL) {
+        // 04 || X || Y big-endian (MODBYTES == fp_bytes for both curves); identity = 04 || 0 || 1
+        le.assign(n * 2 * fb, 0);
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* p = points + i * (2 * fb + 1);
+            if (p[0] != 0x04) { bp_g1vec_free(*out); *out = nullptr; return BP_ERR_ARG; }
+            bool xz = true, y1 = p[2 * fb] == 1;
+            for (int k = 0; k < fb; k++) { if (p[1 + k]) xz = false; if (k < fb - 1 && p[1 + fb + k]) y1 = false; }
+            if (xz && y1) continue;   // identity -> all-zero
+            for (int k = 0; k < fb; k++) { le[i * 2 * fb + k] = p[fb - k]; le[i * 2 * fb + fb + k] = p[2 * fb - k]; }
+        }
+        src = le.data();
+    }
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::upload_points(ctx, src, n, (*out)->d);
+    else rc = Impl<Bn254>::upload_points(ctx, src, n, (*out)->d);
+    if (rc) { bp_g1vec_free(*out); *out = nullptr; }
+    return rc;
+}
+
+int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, int fmt, uint8_t* out) {
+    if (!ctx || !v || (!out && n) || (fmt != BP_FMT_LE && fmt != BP_FMT_AMCL)) return BP_ERR_ARG;
+    if (offset > v->n || n > v->n - offset) return BP_ERR_LENGTH;
+    if (n == 0) return BP_OK;
+    int rc = set_device(ctx); if (rc) return rc;
+    int fb = fp_bytes_of(ctx->curve);
+    std::vector<uint8_t> le;
+    uint8_t* dst = out;
+    if (fmt == BP_FMT_AMCL) { le.resize(n * 2 * fb); dst = le.data(); }
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::download_points(ctx, v->d, offset, n, dst);
+    else rc = Impl<Bn254>::download_points(ctx, v->d, offset, n, dst);
+    if (rc) return rc;
+    if (fmt == BP_FMT_AMCL) {
+        for (size_t i = 0; i < n; i++) {
+            uint8_t* p = out + i * (2 * fb + 1);
+            const uint8_t* q = le.data() + i * 2 * fb;
+            memset(p, 0, 2 * fb + 1);
+            p[0] = 0x04;
+            bool z = true;
+            for (int k = 0; k < 2 * fb; k++) if (q[k]) { z = false; break; }
+            if (z) { p[2 * fb] = 1; continue; }
+            for (int k = 0; k < fb; k++) { p[fb - k] = q[k]; p[2 * fb - k] = q[fb + k]; }
+        }
+    }
+    return BP_OK;
+}
+
+int bp_g1vec_free(bp_g1vec* v) {
+    if (!v) return BP_OK;
+    if (v->owned && v->d) { (void)hipSetDevice(v->ctx->device); (void)hipStreamSynchronize(v->ctx->stream); (void)hipFree(v->d); }
+    delete v;
+    return BP_OK;
+}
+
+size_t bp_g1vec_len(const bp_g1vec* v) { return v ? v->n : 0; }
+void* bp_g1vec_device_ptr(bp_g1vec* v) { return v ? v->d : nullptr; }
+
+int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out) {
+    if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
+    *out = new bp_g1vec{ctx, device_ptr, n, false};
+    return BP_OK;
+}
+
+int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1vec** out) {
+    if (!ctx || !k || !out) return BP_ERR_ARG;
+    if (p && p->n != k->n) return BP_ERR_LENGTH;
+    int rc = bp_g1vec_alloc(ctx, k->n, out);
+    if (rc) return rc;
+    if (k->n == 0) return BP_OK;
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::scalar_mul(ctx, p ? p->d : nullptr, k->d, k->n, (*out)->d);
+    else rc = Impl<Bn254>::scalar_mul(ctx, p ? p->d : nullptr, k->d, k->n, (*out)->d);
+    if (rc) { bp_g1vec_free(*out); *out = nullptr; }
+    return rc;
+}
+
+int bp_g1vec_fixed_base_mul(bp_ctx* ctx, const bp_frvec* k, bp_g1vec** out) { return bp_g1vec_scalar_mul(ctx, nullptr, k, out); }
+
+// ---- FieldElementVector ----
+int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out) {
+    if (!ctx || !out) return BP_ERR_ARG;
+    *out = nullptr;
+    int rc = set_device(ctx); if (rc) return rc;
+    void* d = nullptr;
+    size_t bytes = (n ? n : 1) * 32;
+    HIPCHK(hipMalloc(&d, bytes));
+    if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(d); return BP_ERR_DEVICE; }
+    *out = new bp_frvec{ctx, d, n, true};
+    return BP_OK;
+}
+
+int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec** out) {
+    if (!ctx || !out || (!scalars_le32 && n)) return BP_ERR_ARG;
+    int rc = bp_frvec_alloc(ctx, n, out);
+    if (rc) return rc;
+    if (n == 0) return BP_OK;
+    if (hipMemcpyAsync((*out)->d, scalars_le32, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        bp_frvec_free(*out); *out = nullptr; return BP_ERR_DEVICE;
+    }
+    return BP_OK;
+}
+
+int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, uint8_t* out_le32) {
+    if (!ctx || !v || (!out_le32 && n)) return BP_ERR_ARG;
+    if (offset > v->n || n > v->n - offset) return BP_ERR_LENGTH;
+    if (n == 0) return BP_OK;
+    int rc = set_device(ctx); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out_le32, (const uint8_t*)v->d + offset * 32, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+
+int bp_frvec_free(bp_frvec* v) {
+    if (!v) return BP_OK;
+    if (v->owned && v->d) { (void)hipSetDevice(v->ctx->device); (void)hipStreamSynchronize(v->ctx->stream); (void)hipFree(v->d); }
+    delete v;
+    return BP_OK;
+}
+
+size_t bp_frvec_len(const bp_frvec* v) { return v ? v->n : 0; }
+void* bp_frvec_device_ptr(bp_frvec* v) { return v ? v->d : nullptr; }
+
+int bp_frvec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_frvec** out) {
+    if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
+    *out = new bp_frvec{ctx, device_ptr, n, false};
+    return BP_OK;
+}
+
+// ---- MSM ----
+int bp_msm_g1_range(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n, uint8_t* out_le) {
+    if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
+    if (poff > points->n || n > points->n - poff || soff > scalars->n || n > scalars->n - soff) return BP_ERR_LENGTH;
+    int rc = set_device(ctx); if (rc) return rc;
+    DISPATCH(ctx, I::msm(ctx, points->d, poff, scalars->d, soff, n, out_le));
+}
+
+int bp_msm_g1(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars, uint8_t* out_le) {
+    if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
+    if (points->n != scalars->n) return BP_ERR_LENGTH;
+    return bp_msm_g1_range(ctx, points, 0, scalars, 0, points->n, out_le);
+}
+
+size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {
+    if (!ctx) return 0;
+    int bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
+    MsmGeom g;
+    msm_geom(g, bits, n, ctx->c_override);
+    return (size_t)g.tab.W;
+}
+
+size_t bp_msm_record_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? sizeof(XyzzPacked<Bls381>) : sizeof(XyzzPacked<Bn254>); }
+
+int bp_msm_g1_windows(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n, void* device_out) {
+    if (!ctx || !points || !scalars || !device_out || n == 0) return BP_ERR_ARG;
+    if (poff > points->n || n > points->n - poff || soff > scalars->n || n > scalars->n - soff) return BP_ERR_LENGTH;
+    int rc = set_device(ctx); if (rc) return rc;
+    DISPATCH(ctx, I::msm_windows_to(ctx, points->d, poff, scalars->d, soff, n, device_out));
+}
+
+int bp_msm_g1_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
+    if (!ctx || !device_records || !out_le || sets == 0 || n_per_set == 0) return BP_ERR_ARG;
+    int rc = set_device(ctx); if (rc) return rc;
+    DISPATCH(ctx, I::msm_finish(ctx, device_records, sets, n_per_set, out_le));
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+// bp_curve.cuh -- G1 arithmetic (y^2 = x^3 + b, a = 0) for BLS12-381 and AMCL-BN254, host + gfx950 device.
+//
+// What it replaces: amcl_wrapper::group_elem_g1::G1 as used by the reference -- `G1 + G1`, `&G1 * &Fr`,
+// `binary_scalar_mul`, equality/identity (/root/reference src/ipp.rs:119,125,185,187,255;
+// src/r1cs/prover.rs:358,423,429,550) -- and the point arithmetic inside
+// G1Vector's multi-scalar multiplications (rows a1/a2).
+//
+// Coordinates: XYZZ (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ = 0).  Mixed addition of an
+// affine point costs 8M + 2S against 7M + 4S for Jacobian, and the bucket-sum + bucket-sum addition
+// 12M + 2S against 11M + 5S: XYZZ wins wherever the bucket method spends its time, at the price of 13
+// more VGPRs per accumulator.  Every exceptional case of the incomplete formulas (P + P, P + (-P),
+// identity operands) is handled explicitly: buckets DO see them (duplicate generators, P and -P in one
+// bucket; tests/golden/msm.json holds such cases).
+//
+// Memory forms: AffPacked = x || y packed Montgomery words (96 B for BLS12-381, 64 B for BN254), all-zero
+// = identity ((0,0) is on neither curve); XyzzPacked = 4 packed coordinates.
+#pragma once
+#include "bp_field.cuh"
+
+namespace bp {
+
+struct Bls381 {
+    using Fp = Bls381Fp;
+    using Fr = Bls381Fr;
+    static constexpr int ID = 0;
+    static constexpr int MODBYTES = 48;   // amcl MODBYTES
+    static constexpr uint32_t B = 4;
+    static constexpr uint32_t GX[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                        0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+    static constexpr uint32_t GY[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                        0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+};
+
+struct Bn254 {
+    using Fp = Bn254Fp;
+    using Fr = Bn254Fr;
+    static constexpr int ID = 1;
+    static constexpr int MODBYTES = 32;
+    static constexpr uint32_t B = 2;
+    static constexpr uint32_t GX[8] = {0x00000012u, 0xa7000000u, 0x00000013u, 0x61210000u, 0x00000008u, 0xba344d80u, 0x40000001u, 0x25236482u};
+    static constexpr uint32_t GY[8] = {0x00000001u, 0, 0, 0, 0, 0, 0, 0};
+};
+
+template <class C>
+struct alignas(16) AffPacked {
+    FePacked<typename C::Fp> x, y;
+};
+
+template <class C>
+struct Aff {   // unpacked affine; identity <=> x = y = 0
+    Fe<typename C::Fp> x, y;
+};
+
+template <class C>
+struct Xyzz {
+    Fe<typename C::Fp> x, y, zz, zzz;
+};
+
+template <class C>
+struct alignas(16) XyzzPacked {
+    FePacked<typename C::Fp> x, y, zz, zzz;
+};
+
+template <class C> BP_HD Aff<C> aff_unpack(const AffPacked<C>& p) { Aff<C> r; r.x = fe_unpack(p.x); r.y = fe_unpack(p.y); return r; }
+template <class C> BP_HD AffPacked<C> aff_pack(const Aff<C>& p) { AffPacked<C> r; r.x = fe_pack(p.x); r.y = fe_pack(p.y); return r; }
+template <class C> BP_HD bool aff_is_inf(const Aff<C>& p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
+template <class C> BP_HD Aff<C> aff_neg(const Aff<C>& p) { Aff<C> r; r.x = p.x; r.y = fe_neg(p.y); return r; }   // -(0,0) = (0,0)
+
+template <class C> BP_HD Xyzz<C> xyzz_unpack(const XyzzPacked<C>& p) { Xyzz<C> r; r.x = fe_unpack(p.x); r.y = fe_unpack(p.y); r.zz = fe_unpack(p.zz); r.zzz = fe_unpack(p.zzz); return r; }
+template <class C> BP_HD XyzzPacked<C> xyzz_pack(const Xyzz<C>& p) { XyzzPacked<C> r; r.x = fe_pack(p.x); r.y = fe_pack(p.y); r.zz = fe_pack(p.zz); r.zzz = fe_pack(p.zzz); return r; }
+
+template <class C> BP_HD Xyzz<C> xyzz_inf() {
+    using Fp = typename C::Fp;
+    Xyzz<C> r; r.x = fe_zero<Fp>(); r.y = fe_zero<Fp>(); r.zz = fe_zero<Fp>(); r.zzz = fe_zero<Fp>();
+    return r;
+}
+template <class C> BP_HD bool xyzz_is_inf(const Xyzz<C>& p) { return fe_is_zero(p.zz); }
+
+template <class C> BP_HD Xyzz<C> xyzz_from_aff(const Aff<C>& p) {
+    using Fp = typename C::Fp;
+    if (aff_is_inf(p)) return xyzz_inf<C>();
+    Xyzz<C> r; r.x = p.x; r.y = p.y; r.zz = fe_one<Fp>(); r.zzz = fe_one<Fp>();
+    return r;
+}
+
+// 2 * (affine p), p != identity: mdbl-2008-s-1 (a = 0)
+template <class C> BP_HD Xyzz<C> xyzz_dbl_aff(const Aff<C>& p) {
+    using Fp = typename C::Fp;
+    Fe<Fp> U = fe_dbl(p.y);
+    Fe<Fp> V = fe_sqr(U);
+    Fe<Fp> W = fe_mul(U, V);
+    Fe<Fp> S = fe_mul(p.x, V);
+    Fe<Fp> X2 = fe_sqr(p.x);
+    Fe<Fp> M = fe_add(fe_dbl(X2), X2);
+    Xyzz<C> r;
+    r.x = fe_sub(fe_sub(fe_sqr(M), S), S);
+    r.y = fe_sub(fe_mul(M, fe_sub(S, r.x)), fe_mul(W, p.y));
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+
+// 2 * p: dbl-2008-s-1 (a = 0).  (y = 0 cannot occur: both groups have odd order.)
+template <class C> BP_HD Xyzz<C> xyzz_dbl(const Xyzz<C>& p) {
+    using Fp = typename C::Fp;
+    if (xyzz_is_inf(p)) return p;
+    Fe<Fp> U = fe_dbl(p.y);
+    Fe<Fp> V = fe_sqr(U);
+    Fe<Fp> W = fe_mul(U, V);
+    Fe<Fp> S = fe_mul(p.x, V);
+    Fe<Fp> X2 = fe_sqr(p.x);
+    Fe<Fp> M = fe_add(fe_dbl(X2), X2);
+    Xyzz<C> r;
+    r.x = fe_sub(fe_sub(fe_sqr(M), S), S);
+    r.y = fe_sub(fe_mul(M, fe_sub(S, r.x)), fe_mul(W, p.y));
+    r.zz = fe_mul(V, p.zz);
+    r.zzz = fe_mul(W, p.zzz);
+    return r;
+}
+
+// acc + (affine q): madd-2008-s, exceptional cases handled.
+template <class C> BP_HD Xyzz<C> xyzz_add_aff(const Xyzz<C>& a, const Aff<C>& q) {
+    using Fp = typename C::Fp;
+    if (aff_is_inf(q)) return a;
+    if (xyzz_is_inf(a)) return xyzz_from_aff(q);
+    Fe<Fp> U2 = fe_mul(q.x, a.zz);
+    Fe<Fp> S2 = fe_mul(q.y, a.zzz);
+    Fe<Fp> Pp = fe_sub(U2, a.x);
+    Fe<Fp> Rr = fe_sub(S2, a.y);
+    if (fe_is_zero(Pp)) {
+        if (fe_is_zero(Rr)) return xyzz_dbl_aff(q);
+        return xyzz_inf<C>();
+    }
+    Fe<Fp> PP = fe_sqr(Pp);
+    Fe<Fp> PPP = fe_mul(Pp, PP);
+    Fe<Fp> Q = fe_mul(a.x, PP);
+    Xyzz<C> r;
+    r.x = fe_sub(fe_sub(fe_sub(fe_sqr(Rr), PPP), Q), Q);
+    r.y = fe_sub(fe_mul(Rr, fe_sub(Q, r.x)), fe_mul(a.y, PPP));
+    r.zz = fe_mul(a.zz, PP);
+    r.zzz = fe_mul(a.zzz, PPP);
+    return r;
+}
+
+// a + b: add-2008-s, exceptional cases handled.
+template <class C> BP_HD Xyzz<C> xyzz_add(const Xyzz<C>& a, const Xyzz<C>& b) {
+    using Fp = typename C::Fp;
+    if (xyzz_is_inf(b)) return a;
+    if (xyzz_is_inf(a)) return b;
+    Fe<Fp> U1 = fe_mul(a.x, b.zz);
+    Fe<Fp> U2 = fe_mul(b.x, a.zz);
+    Fe<Fp> S1 = fe_mul(a.y, b.zzz);
+    Fe<Fp> S2 = fe_mul(b.y, a.zzz);
+    Fe<Fp> Pp = fe_sub(U2, U1);
+    Fe<Fp> Rr = fe_sub(S2, S1);
+    if (fe_is_zero(Pp)) {
+        if (fe_is_zero(Rr)) return xyzz_dbl(a);
+        return xyzz_inf<C>();
+    }
+    Fe<Fp> PP = fe_sqr(Pp);
+    Fe<Fp> PPP = fe_mul(Pp, PP);
+    Fe<Fp> Q = fe_mul(U1, PP);
+    Xyzz<C> r;
+    r.x = fe_sub(fe_sub(fe_sub(fe_sqr(Rr), PPP), Q), Q);
+    r.y = fe_sub(fe_mul(Rr, fe_sub(Q, r.x)), fe_mul(S1, PPP));
+    r.zz = fe_mul(fe_mul(a.zz, b.zz), PP);
+    r.zzz = fe_mul(fe_mul(a.zzz, b.zzz), PPP);
+    return r;
+}
+
+template <class C> BP_HD Xyzz<C> xyzz_neg(const Xyzz<C>& p) { Xyzz<C> r = p; r.y = fe_neg(p.y); return r; }
+
+// -> affine.  One field inversion (of ZZ * ZZZ).
+template <class C> BP_HD_NOINLINE Aff<C> xyzz_to_aff(const Xyzz<C>& p) {
+    using Fp = typename C::Fp;
+    Aff<C> r;
+    if (xyzz_is_inf(p)) { r.x = fe_zero<Fp>(); r.y = fe_zero<Fp>(); return r; }
+    Fe<Fp> i5 = fe_inv<Fp>(fe_mul(p.zz, p.zzz));
+    r.x = fe_mul(p.x, fe_mul(i5, p.zzz));   // X / ZZ
+    r.y = fe_mul(p.y, fe_mul(i5, p.zz));    // Y / ZZZ
+    return r;
+}
+
+// y^2 == x^3 + b ?  (identity counts as on the curve)
+template <class C> BP_HD bool aff_on_curve(const Aff<C>& p) {
+    using Fp = typename C::Fp;
+    if (aff_is_inf(p)) return true;
+    Fe<Fp> braw = fe_zero<Fp>();
+    braw.v[0] = C::B;
+    Fe<Fp> rhs = fe_add(fe_mul(fe_sqr(p.x), p.x), fe_to_mont<Fp>(braw));
+    return fe_eq(fe_sqr(p.y), rhs);
+}
+
+template <class C> BP_HD Aff<C> generator() {
+    using Fp = typename C::Fp;
+    Aff<C> g;
+    g.x = fe_to_mont<Fp>(fe_unpack_words<Fp>(C::GX));
+    g.y = fe_to_mont<Fp>(fe_unpack_words<Fp>(C::GY));
+    return g;
+}
+
+// k * p, k given as NW canonical (non-Montgomery) 32-bit words; plain double-and-add, variable time.
+template <class C> BP_HD_NOINLINE Xyzz<C> xyzz_mul_words(const uint32_t* k, const Aff<C>& p) {
+    Xyzz<C> acc = xyzz_inf<C>();
+    int top = C::Fr::BITS - 1;
+    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
+    for (int i = top; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_add_aff(acc, p);
+    }
+    return acc;
+}
+
+}  // namespace bp

@@ -1,0 +1,326 @@
+// bp_field.cuh -- prime-field arithmetic for BLS12-381 / AMCL-BN254, host + gfx950 device.
+//
+// What it replaces: the BIG/FP limb arithmetic that the reference reaches through
+// amcl_wrapper::field_elem::FieldElement (`* + - negation square inverse`, /root/reference
+// src/ipp.rs:113,116-117,179,182-183,297-298) and, one level down, the Fp arithmetic under every
+// G1 operation.
+//
+// Design (MI355X, measured -- microbench/instr_rate.hip, microbench/fpmul_rate.hip):
+//   * gfx950 issues v_mad_u64_u32 at half rate (~4.5 cyc / wave64) and EVERY carry instruction
+//     (v_add_co/v_addc_co, v_lshl_add_u64) at that same half rate; only plain VOP2 ops are full rate.
+//     A saturated 12x32-bit CIOS therefore spends as much time propagating carries as multiplying
+//     (4.4e10 Fp-mul/s chip-wide), a column-wise mad+addc form 5.9e10.
+//   * So: UNSATURATED 30-bit limbs in 32-bit VGPRs (13 limbs for the 381-bit Fp, 9 for the 254/255-bit
+//     fields).  A column of up to 13 products of 30x30 bits fits a 64-bit accumulator, so a whole
+//     column is a pure chain of v_mad_u64_u32 with zero carry instructions; one v_and + one 64-bit shift
+//     per column extracts the limb.  6.6e10 Fp-mul/s chip-wide, and the least sensitive to occupancy.
+//   * One element per lane, entirely in VGPRs.  No MFMA: in a*b both operands differ per lane, there
+//     is no shared matrix operand to contract against (north_star: integer path, no MFMA).
+//   * In HBM an element is PACKED: canonical residue (in Montgomery form, R = 2^(30 NL)) as NW
+//     little-endian 32-bit words (12 words = 48 B for Fp381), so a G1 affine point is 96 B and is moved
+//     with 16-byte vector loads.  pack()/unpack() convert at the load/store boundary (~2 ops/limb).
+//
+// Discipline ("strict"): every function takes and returns fully reduced elements (value in [0, p),
+// every limb < 2^30).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BP_HD __host__ __device__ __forceinline__
+#define BP_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define BP_HD inline
+#define BP_HD_NOINLINE
+#endif
+
+namespace bp {
+
+constexpr int LB = 30;                       // limb bits
+constexpr uint32_t LMASK = (1u << LB) - 1;
+
+// ----------------------------------------------------------------------------------------------- moduli
+// Little-endian 32-bit words of each modulus (public parameters; cross-checked against
+// tests/golden/curves.json by tests/test_capi_cpu.py through bp_curve_params()).
+
+struct Bls381FpW {
+    static constexpr int NW = 12, BITS = 381;
+    static constexpr uint32_t MODW[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                          0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+};
+struct Bls381FrW {
+    static constexpr int NW = 8, BITS = 255;
+    static constexpr uint32_t MODW[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+};
+// AMCL "BN254" = Nogami curve, u = -(2^62 + 2^55 + 1)  
+struct Bn254FpW {
+    static constexpr int NW = 8, BITS = 254;
+    static constexpr uint32_t MODW[8] = {0x00000013u, 0xa7000000u, 0x00000013u, 0x61210000u, 0x00000008u, 0xba344d80u, 0x40000001u, 0x25236482u};
+};
+struct Bn254FrW {
+    static constexpr int NW = 8, BITS = 254;
+    static constexpr uint32_t MODW[8] = {0x0000000du, 0xa1000000u, 0x00000010u, 0xff9f8000u, 0x00000007u, 0xba344d80u, 0x40000001u, 0x25236482u};
+};
+
+// ----------------------------------------------------------------------------------------------- constants
+template <int NL>
+struct LimbConsts {
+    uint32_t mod[NL];   // p
+    uint32_t one[NL];   // R mod p,   R = 2^(30 NL)
+    uint32_t r2[NL];    // R^2 mod p
+    uint32_t inv;       // -p^-1 mod 2^30
+};
+
+template <class W>
+struct Field {
+    using Words = W;
+    static constexpr int NW = W::NW;                       // packed 32-bit words
+    static constexpr int BITS = W::BITS;
+    static constexpr int NL = (W::BITS + 2 + LB - 1) / LB;  // 30-bit limbs; R >= 4p
+    static_assert(NL <= 15, "column accumulators would overflow 64 bits");
+    static_assert(NL * LB <= NW * 32 + 32, "limb/word geometry");
+
+    static constexpr LimbConsts<NL> make() {
+        LimbConsts<NL> c{};
+        for (int i = 0; i < NL; i++) {
+            int bit = LB * i, w = bit / 32, o = bit % 32;
+            uint64_t v = (w < NW ? (uint64_t)W::MODW[w] : 0) >> o;
+            if (w + 1 < NW) v |= ((uint64_t)W::MODW[w + 1] << 32) >> o;
+            c.mod[i] = (uint32_t)(v & LMASK);
+        }
+        uint32_t x = 1;
+        for (int i = 0; i < 6; i++) x *= 2 - c.mod[0] * x;
+        c.inv = (0u - x) & LMASK;
+        // t = 2^k mod p by modular doubling
+        uint32_t t[NL] = {};
+        t[0] = 1;
+        for (int k = 0; k < 2 * NL * LB; k++) {
+            uint32_t carry = 0;
+            for (int i = 0; i < NL; i++) { uint32_t v = (t[i] << 1) | carry; carry = v >> LB; t[i] = v & LMASK; }
+            // t < 2p < 2^(30 NL): compare with p
+            bool ge = true;
+            for (int i = NL - 1; i >= 0; i--) { if (t[i] != c.mod[i]) { ge = t[i] > c.mod[i]; break; } }
+            if (ge) { uint32_t br = 0; for (int i = 0; i < NL; i++) { uint32_t v = t[i] - c.mod[i] - br; br = v >> 31; t[i] = v & LMASK; } }
+            if (k == NL * LB - 1) for (int i = 0; i < NL; i++) c.one[i] = t[i];
+        }
+        for (int i = 0; i < NL; i++) c.r2[i] = t[i];
+        return c;
+    }
+    static constexpr LimbConsts<NL> C = make();
+};
+
+using Bls381Fp = Field<Bls381FpW>;
+using Bls381Fr = Field<Bls381FrW>;
+using Bn254Fp = Field<Bn254FpW>;
+using Bn254Fr = Field<Bn254FrW>;
+
+// ----------------------------------------------------------------------------------------------- element
+template <class P>
+struct Fe {
+    uint32_t v[P::NL];
+};
+
+// Packed memory form: NW little-endian 32-bit words.
+template <class P>
+struct alignas(16) FePacked {
+    uint32_t w[P::NW];
+};
+
+template <class P> BP_HD Fe<P> fe_zero() { Fe<P> r; for (int i = 0; i < P::NL; i++) r.v[i] = 0; return r; }
+template <class P> BP_HD Fe<P> fe_one() { Fe<P> r; for (int i = 0; i < P::NL; i++) r.v[i] = P::C.one[i]; return r; }
+
+template <class P> BP_HD bool fe_is_zero(const Fe<P>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) o |= a.v[i];
+    return o == 0;
+}
+
+template <class P> BP_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+
+// words (value < 2^(32 NW)) -> limbs.  No reduction.
+template <class P> BP_HD Fe<P> fe_unpack_words(const uint32_t* w) {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        const int bit = LB * i, k = bit / 32, o = bit % 32;
+        uint64_t v = (k < P::NW ? (uint64_t)w[k] : 0);
+        if (k + 1 < P::NW) v |= (uint64_t)w[k + 1] << 32;
+        r.v[i] = (uint32_t)(v >> o) & LMASK;
+    }
+    return r;
+}
+
+// limbs (normalised) -> words
+template <class P> BP_HD void fe_pack_words(uint32_t* w, const Fe<P>& a) {
+#pragma unroll
+    for (int k = 0; k < P::NW; k++) {
+        const int bit = 32 * k, i = bit / LB, o = bit % LB;
+        uint64_t v = (uint64_t)a.v[i] >> o;
+        if (i + 1 < P::NL) v |= (uint64_t)a.v[i + 1] << (LB - o);
+        if (i + 2 < P::NL && 2 * LB - o < 32) v |= (uint64_t)a.v[i + 2] << (2 * LB - o);
+        w[k] = (uint32_t)v;
+    }
+}
+
+template <class P> BP_HD Fe<P> fe_unpack(const FePacked<P>& p) { return fe_unpack_words<P>(p.w); }
+template <class P> BP_HD FePacked<P> fe_pack(const Fe<P>& a) { FePacked<P> r; fe_pack_words<P>(r.w, a); return r; }
+
+// a (< 2p, limbs normalised) -> a mod p
+template <class P> BP_HD void fe_cond_sub_p(uint32_t* a) {
+    uint32_t d[P::NL];
+    uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        uint32_t x = a[i] - P::C.mod[i] - br;
+        br = x >> 31;
+        d[i] = x & LMASK;
+    }
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) a[i] = br ? a[i] : d[i];
+}
+
+template <class P> BP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        uint32_t x = a.v[i] + b.v[i] + c;
+        r.v[i] = x & LMASK;
+        c = x >> LB;
+    }
+    fe_cond_sub_p<P>(r.v);   // a + b < 2p < 2^(30 NL): no carry out of the top limb
+    return r;
+}
+
+template <class P> BP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        uint32_t x = a.v[i] - b.v[i] - br;
+        br = x >> 31;
+        r.v[i] = x & LMASK;
+    }
+    uint32_t mask = 0u - br;   // negative -> add p back
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        uint32_t x = r.v[i] + (P::C.mod[i] & mask) + c;
+        r.v[i] = x & LMASK;
+        c = x >> LB;
+    }
+    return r;
+}
+
+template <class P> BP_HD Fe<P> fe_neg(const Fe<P>& a) { return fe_sub<P>(fe_zero<P>(), a); }
+template <class P> BP_HD Fe<P> fe_dbl(const Fe<P>& a) { return fe_add<P>(a, a); }
+
+// Montgomery reduction of 2*NL normalised limbs t (value < p * R) -> t / R mod p, product scanning.
+template <class P> BP_HD Fe<P> fe_mont_reduce(const uint32_t* t) {
+    constexpr int N = P::NL;
+    uint32_t m[N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        acc += t[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
+        acc += (uint64_t)m[k] * P::C.mod[0];
+        acc >>= LB;
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int k = N; k < 2 * N; k++) {
+        acc += t[k];
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        r.v[k - N] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    fe_cond_sub_p<P>(r.v);
+    return r;
+}
+
+// Montgomery product a*b/R mod p.
+template <class P> BP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::NL;
+    uint32_t t[2 * N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+        t[k] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    t[2 * N - 1] = (uint32_t)acc;
+    return fe_mont_reduce<P>(t);
+}
+
+// Montgomery square: cross products taken once against a doubled operand (2 a_i < 2^31; a column of
+// <= 6 doubled cross terms + 1 square stays below 2^64).
+template <class P> BP_HD Fe<P> fe_sqr(const Fe<P>& a) {
+    constexpr int N = P::NL;
+    uint32_t a2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) a2[i] = a.v[i] << 1;
+    uint32_t t[2 * N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        t[k] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    t[2 * N - 1] = (uint32_t)acc;
+    return fe_mont_reduce<P>(t);
+}
+
+template <class P> BP_HD Fe<P> fe_to_mont(const Fe<P>& raw) {
+    Fe<P> r2;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) r2.v[i] = P::C.r2[i];
+    return fe_mul<P>(raw, r2);
+}
+
+template <class P> BP_HD Fe<P> fe_from_mont(const Fe<P>& a) {
+    uint32_t t[2 * P::NL];
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) { t[i] = a.v[i]; t[P::NL + i] = 0; }
+    return fe_mont_reduce<P>(t);
+}
+
+// a^(p-2); inverse of 0 is 0.  Long and cold: kept out of line.
+template <class P> BP_HD_NOINLINE Fe<P> fe_inv(const Fe<P>& a) {
+    uint32_t e[P::NW];
+    for (int i = 0; i < P::NW; i++) e[i] = P::Words::MODW[i];
+    {   // e = p - 2 (BLS12-381's r ends in ...00000001, so the borrow can run)
+        uint32_t br = 2;
+        for (int i = 0; i < P::NW && br; i++) { uint32_t o = e[i]; e[i] = o - br; br = o < br; }
+    }
+    Fe<P> acc = fe_one<P>();
+    for (int i = P::BITS - 1; i >= 0; i--) {
+        acc = fe_sqr<P>(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul<P>(acc, a);
+    }
+    return acc;
+}
+
+// canonical words < p ?
+template <class P> BP_HD bool words_lt_mod(const uint32_t* a) {
+    for (int i = P::NW - 1; i >= 0; i--) {
+        if (a[i] < P::Words::MODW[i]) return true;
+        if (a[i] > P::Words::MODW[i]) return false;
+    }
+    return false;
+}
+
+}  // namespace bp

@@ -1,0 +1,417 @@
+// bp_kernels.cuh -- gfx950 kernels of the Pippenger bucket MSM and the vector helpers around it.
+//
+// Replaces (device side of): G1Vector::multi_scalar_mul_var_time / inner_product_var_time_with_ref_vecs /
+// inner_product_const_time of amcl_wrapper as called at /root/reference src/ipp.rs:91,104,158,170,251-253 and
+// src/r1cs/prover.rs:358,423, src/r1cs/verifier.rs:451.  The reference's CPU path is
+// believed to be Strauss/wNAF; the bucket method is this build's choice -- parity is on the
+// resulting group element.
+//
+// Pipeline for  sum_i s_i P_i  with W signed windows of (nearly) equal width c covering bits+1 bits, window w
+// owning 2^(c_w - 1) buckets (bucket j <-> |digit| = j + 1):
+//   k_digits_count   thread per scalar: k' = k + bias, 16-bit digit code per window (stored transposed,
+//                    code[w][i]) and histogram of (window, |digit|) -> count[]
+//   k_scan_*         exclusive scan of count[] -> bucket start offsets (+ copy = scatter cursors)
+//   k_digits_scatter grid (tiles, W), window-major: claim a slot per (window, |digit|), write point index (+ sign
+//                    bit) -> idx[]   (order inside a bucket is arbitrary: the sum is commutative and the result is
+//                    compared in canonical affine form)
+//   k_task_*         cut buckets into tasks of <= kTaskLen points, order tasks longest first
+//   k_accumulate     lane per task: XYZZ accumulator in VGPRs, gathers its points (96-B rows, 16-B vector loads) and
+//                    mixed-adds them
+//   k_combine_heavy  block per multi-task bucket: tree over its task sums
+//   k_bucket_reduce  thread per m consecutive buckets: running sum / sum of running sums, weighted by the
+//                    segment's base value, then an LDS tree per block            -> partial[]
+//   k_window_sums    block per window: tree over the partials                    -> window_sum[W]
+// The final  sum_w 2^(off_w) window_sum[w]  (a strictly serial chain of ~bits doublings) is folded on the host
+// (bp_capi.hip): one lane of a GPU would take ~2 ms for it, the host ~0.1 ms, and the result is needed on the
+// host anyway (it goes into the Fiat-Shamir transcript).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bp_curve.cuh"
+
+namespace bp {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------- scalar slicing
+// Scalars in HBM: 8 canonical (non-Montgomery) little-endian 32-bit words, 32 B, loaded as two 16-B vectors.
+struct alignas(16) ScalarWords {
+    uint32_t w[8];
+};
+
+// Window table: W windows of (nearly equal) widths cw[w] covering fr_bits + 1 bits, window w starting at bit
+// off[w]; window w owns buckets boff[w] .. boff[w+1]-1 (2^(cw-1) of them, bucket j <-> |digit| = j + 1).
+// Equal widths matter: a narrow top window would put n / 2^(few bits) points into each of its buckets.
+constexpr int kMaxWindows = 128;
+struct WinTab {
+    int W;
+    uint32_t nbuckets;
+    uint8_t cw[kMaxWindows];
+    uint16_t off[kMaxWindows];
+    uint32_t boff[kMaxWindows + 1];
+    ScalarWords bias;   // H = sum_w (2^(cw-1) - 1) 2^off[w]
+};
+
+// Signed-digit recoding without a serial carry: with k' = k + H, the raw cw-bit window w of k' equals
+// digit_w + (2^(cw-1) - 1), digit_w in [-(2^(cw-1) - 1), 2^(cw-1)], sum_w digit_w 2^off[w] = k.  (Adding
+// half-1 to a window overflows it exactly when the classic recoding would emit a carry.)  The raw window --
+// at most 16 bits -- is the "digit code" stored per (window, scalar).
+__device__ __forceinline__ void add256(uint64_t (&q)[4], const ScalarWords& a, const ScalarWords& b) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint64_t x = a.w[2 * i] | ((uint64_t)a.w[2 * i + 1] << 32), y = b.w[2 * i] | ((uint64_t)b.w[2 * i + 1] << 32);
+        uint64_t s = x + y, s2 = s + c;
+        c = (uint64_t)(s < x) + (uint64_t)(s2 < s);
+        q[i] = s2;
+    }
+}
+
+// thread per scalar: digit codes (transposed: code[w][i]) + histogram of (window, |digit|)
+__global__ void __launch_bounds__(kBlock) k_digits_count(const ScalarWords* __restrict__ scalars, size_t n, WinTab tab,
+                                                          uint16_t* __restrict__ code, uint32_t* __restrict__ count) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t q[4];
+        add256(q, scalars[i], tab.bias);
+        for (int w = 0; w < tab.W; w++) {
+            int c = tab.cw[w];
+            uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);
+            q[0] = (q[0] >> c) | (q[1] << (64 - c));
+            q[1] = (q[1] >> c) | (q[2] << (64 - c));
+            q[2] = (q[2] >> c) | (q[3] << (64 - c));
+            q[3] >>= c;
+            code[(size_t)w * n + i] = (uint16_t)raw;
+            int d = (int)raw - ((1 << (c - 1)) - 1);
+            if (d != 0) atomicAdd(&count[tab.boff[w] + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+        }
+    }
+}
+
+// grid = (tiles, W): window-major, so that the blocks in flight write one window's slice of idx[] (n words,
+// L2-sized) instead of W slices at once.
+__global__ void __launch_bounds__(kBlock) k_digits_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab,
+                                                            uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
+    int w = blockIdx.y;
+    int c = tab.cw[w];
+    uint32_t base = tab.boff[w];
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int d = (int)code[(size_t)w * n + i] - ((1 << (c - 1)) - 1);
+        if (d != 0) {
+            uint32_t slot = atomicAdd(&cursor[base + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+            idx[slot] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- exclusive scan
+constexpr int kScanPerThread = 8;
+constexpr int kScanPerBlock = kBlock * kScanPerThread;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* lds /* >= 4 words */, uint32_t& block_total) {
+    // inclusive scan inside the wave by shuffles, then across the block's 4 waves through LDS
+    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; k++) { uint32_t t = lds[k]; if ((uint32_t)k < wave) base += t; tot += t; }
+    __syncthreads();
+    block_total = tot;
+    return base + inc - mine;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds[kBlock / 64];
+    size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) if (base + j < n) s += in[base + j];
+    uint32_t tot;
+    block_exclusive_scan(s, lds, tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of up to kScanPerBlock * k block sums, in place
+__global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict__ block_sums, size_t nblocks) {
+    __shared__ uint32_t lds[kBlock / 64];
+    uint32_t carry = 0;
+    for (size_t chunk = 0; chunk < nblocks; chunk += kScanPerBlock) {
+        size_t base = chunk + (size_t)threadIdx.x * kScanPerThread;
+        uint32_t v[kScanPerThread], s = 0;
+#pragma unroll
+        for (int j = 0; j < kScanPerThread; j++) { v[j] = base + j < nblocks ? block_sums[base + j] : 0; s += v[j]; }
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan(s, lds, tot) + carry;
+#pragma unroll
+        for (int j = 0; j < kScanPerThread; j++) { if (base + j < nblocks) block_sums[base + j] = ex; ex += v[j]; }
+        carry += tot;
+    }
+}
+
+// out[i] = exclusive prefix of in; optionally also writes a copy (the scatter cursors).  in/out may alias.
+__global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in, size_t n, const uint32_t* __restrict__ block_sums,
+                                                        uint32_t* out, uint32_t* __restrict__ out_copy) {
+    __shared__ uint32_t lds[kBlock / 64];
+    size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread], s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(s, lds, tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) {
+        if (base + j < n) { out[base + j] = ex; if (out_copy) out_copy[base + j] = ex; }
+        ex += v[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- tasks
+// A bucket of `size` points is cut into ceil(size / kTaskLen) tasks of at most kTaskLen points, so that no lane
+// ever walks more than kTaskLen points (structured scalars -- bit vectors, repeated values -- put thousands of
+// points into one bucket).  Tasks are then ordered by length, longest first (counting sort), so that the 64
+// lanes of a wave run the same number of additions: with Poisson(32) bucket sizes an unsorted wave waits for
+// its longest lane, ~1.45x the mean.
+// The task length L is a power of two >= 128 chosen per call (>= 2x the mean bucket size, so that with uniformly
+// random scalars every bucket is a single task); lengths are binned into 129 classes, longest first.
+constexpr uint32_t kTaskBins = 129;
+__device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = log2(L) - 7
+
+// thread per bucket: ntasks[g], and a histogram of task lengths
+__global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
+                                                        uint32_t L, uint32_t lshift, uint32_t* __restrict__ ntasks, uint32_t* __restrict__ bin_count) {
+    __shared__ uint32_t lh[kTaskBins];
+    for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
+    __syncthreads();
+    uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g < nbuckets) {
+        uint32_t size = end[g] - start[g];
+        uint32_t full = size / L, rem = size % L;
+        ntasks[g] = full + (rem ? 1 : 0);
+        if (full) atomicAdd(&lh[0], full);
+        if (rem) atomicAdd(&lh[task_bin(rem, L, lshift)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) if (lh[b]) atomicAdd(&bin_count[b], lh[b]);
+}
+
+// single block: bin_count -> exclusive offsets (in place); total task count -> *total
+__global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __restrict__ bin, uint32_t* __restrict__ total) {
+    __shared__ uint32_t lds[kBlock / 64];
+    static_assert(kTaskBins <= kBlock, "one thread per bin");
+    uint32_t v = threadIdx.x < kTaskBins ? bin[threadIdx.x] : 0, tot;
+    uint32_t ex = block_exclusive_scan(v, lds, tot);
+    if (threadIdx.x < kTaskBins) bin[threadIdx.x] = ex;
+    if (threadIdx.x == 0) *total = tot;
+}
+
+// thread per bucket: emit its tasks.  task id = task_off[g] + k; order[] lists task ids longest first.
+// t_start/t_len describe the slot range of a task.  Buckets with more than one task are appended to heavy[].
+__global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
+                                                       uint32_t L, uint32_t lshift, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ bin_cursor,
+                                                       uint32_t* __restrict__ order, uint32_t* __restrict__ t_start, uint32_t* __restrict__ t_len,
+                                                       uint32_t* __restrict__ heavy, uint32_t* __restrict__ nheavy) {
+    __shared__ uint32_t lh[kTaskBins], lbase[kTaskBins];
+    for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
+    __syncthreads();
+    uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t size = 0, s0 = 0, toff = 0, rank = 0, bin = 0;
+    bool single = false;
+    if (g < nbuckets) {
+        s0 = start[g];
+        size = end[g] - s0;
+        toff = task_off[g];
+        if (size > 0 && size <= L) {                  // the common case: one task, ranked inside the block
+            single = true;
+            bin = task_bin(size, L, lshift);
+            rank = atomicAdd(&lh[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lbase[b] = lh[b] ? atomicAdd(&bin_cursor[b], lh[b]) : 0;
+    __syncthreads();
+    if (single) {
+        order[lbase[bin] + rank] = toff;
+        t_start[toff] = s0;
+        t_len[toff] = size;
+    } else if (size > L) {                           // rare: a heavy bucket emits its tasks with global atomics
+        uint32_t nt = (size + L - 1) / L;
+        uint32_t nfull = size / L;
+        uint32_t pos0 = nfull ? atomicAdd(&bin_cursor[0], nfull) : 0;   // all full-length tasks in one reservation
+        for (uint32_t k = 0; k < nt; k++) {
+            uint32_t len = size - k * L < L ? size - k * L : L;
+            uint32_t pos = k < nfull ? pos0 + k : atomicAdd(&bin_cursor[task_bin(len, L, lshift)], 1u);
+            order[pos] = toff + k;
+            t_start[toff + k] = s0 + k * L;
+            t_len[toff + k] = len;
+        }
+        heavy[atomicAdd(nheavy, 1u)] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- bucket accumulate
+// One lane per task.  The accumulator (4 x 13 limbs) lives in VGPRs for the whole run; points are gathered as
+// 96-byte rows with 16-byte vector loads.  tsum[task] receives the task's sum.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_accumulate(const AffPacked<C>* __restrict__ pts, const uint32_t* __restrict__ idx,
+                                                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ t_start,
+                                                       const uint32_t* __restrict__ t_len, const uint32_t* __restrict__ total_tasks,
+                                                       XyzzPacked<C>* __restrict__ tsum) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *total_tasks) return;
+    uint32_t tid = order[j];
+    uint32_t s = t_start[tid], e = s + t_len[tid];
+    Xyzz<C> acc = xyzz_inf<C>();
+    for (; s < e; s++) {
+        uint32_t code = idx[s];
+        Aff<C> p = aff_unpack(pts[code & 0x7fffffffu]);
+        if (code >> 31) p.y = fe_neg(p.y);
+        acc = xyzz_add_aff(acc, p);
+    }
+    tsum[tid] = xyzz_pack(acc);
+}
+
+// ---------------------------------------------------------------------------------------------- bucket reduce
+// LDS tree over the block's kBlock partial sums (packed, 4*NW words each); result valid in thread 0.
+template <class C>
+__device__ __forceinline__ Xyzz<C> block_tree_sum(Xyzz<C> mine, XyzzPacked<C>* lds) {
+    lds[threadIdx.x] = xyzz_pack(mine);
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            mine = xyzz_add(mine, xyzz_unpack(lds[threadIdx.x + s]));
+            lds[threadIdx.x] = xyzz_pack(mine);
+        }
+        __syncthreads();
+    }
+    return mine;
+}
+
+// One wave per heavy bucket (grid = an upper bound; surplus waves exit): sum of its tasks -> tsum[task_off[g]].
+template <class C>
+__global__ void __launch_bounds__(64) k_combine_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ nheavy,
+                                                      const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks,
+                                                      XyzzPacked<C>* __restrict__ tsum) {
+    __shared__ XyzzPacked<C> lds[64];
+    if (blockIdx.x >= *nheavy) return;
+    uint32_t g = heavy[blockIdx.x];
+    uint32_t t0 = task_off[g], nt = ntasks[g];
+    Xyzz<C> mine = xyzz_inf<C>();
+    for (uint32_t k = threadIdx.x; k < nt; k += 64) mine = xyzz_add(mine, xyzz_unpack(tsum[t0 + k]));
+    lds[threadIdx.x] = xyzz_pack(mine);
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && threadIdx.x + s < nt) {
+            mine = xyzz_add(mine, xyzz_unpack(lds[threadIdx.x + s]));
+            lds[threadIdx.x] = xyzz_pack(mine);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tsum[t0] = xyzz_pack(mine);
+}
+
+// small * p by double-and-add (small < 2^16)
+template <class C>
+__device__ __forceinline__ Xyzz<C> xyzz_mul_small(uint32_t k, const Xyzz<C>& p) {
+    Xyzz<C> acc = xyzz_inf<C>();
+    if (k == 0) return acc;
+    int top = 31 - __clz(k);
+    for (int i = top; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k >> i) & 1) acc = xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+// grid = (max blocks per window, W).  Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket
+// indices t*m .. t*m + m - 1, and produces  sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
+// Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
+                                                          const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t m,
+                                                          XyzzPacked<C>* __restrict__ partial) {
+    __shared__ XyzzPacked<C> lds[kBlock];
+    uint32_t w = blockIdx.y;
+    uint32_t B = tab.boff[w + 1] - tab.boff[w];
+    uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t T = (B + m - 1) / m;
+    if (blockIdx.x * kBlock >= T) {   // whole block beyond this window's buckets
+        if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = xyzz_pack(xyzz_inf<C>());
+        return;
+    }
+    Xyzz<C> mine = xyzz_inf<C>();
+    if (t < T) {
+        Xyzz<C> run = xyzz_inf<C>(), tri = xyzz_inf<C>();
+        uint32_t lo = t * m, hi = lo + m < B ? lo + m : B;
+        for (uint32_t j = hi; j-- > lo;) {
+            uint32_t g = tab.boff[w] + j;
+            if (ntasks[g]) run = xyzz_add(run, xyzz_unpack(tsum[task_off[g]]));
+            tri = xyzz_add(tri, run);
+        }
+        mine = xyzz_add(tri, xyzz_mul_small<C>(lo, run));
+    }
+    mine = block_tree_sum<C>(mine, lds);
+    if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = xyzz_pack(mine);
+}
+
+// grid = W blocks: window_sum[w] = sum of partial[w][0..per_window)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, uint32_t per_window,
+                                                        XyzzPacked<C>* __restrict__ window_sum) {
+    __shared__ XyzzPacked<C> lds[kBlock];
+    uint32_t w = blockIdx.x;
+    Xyzz<C> mine = xyzz_inf<C>();
+    for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_add(mine, xyzz_unpack(partial[(size_t)w * per_window + j]));
+    mine = block_tree_sum<C>(mine, lds);
+    if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
+}
+
+// ---------------------------------------------------------------------------------------------- conversions
+// canonical LE words (x || y per point) <-> resident packed Montgomery affine
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_points_to_resident(const uint32_t* __restrict__ raw, size_t n, AffPacked<C>* __restrict__ out) {
+    using Fp = typename C::Fp;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = raw + i * 2 * Fp::NW;
+    uint32_t xw[Fp::NW], yw[Fp::NW];
+    for (int k = 0; k < Fp::NW; k++) { xw[k] = p[k]; yw[k] = p[Fp::NW + k]; }
+    Aff<C> a;
+    a.x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
+    a.y = fe_to_mont<Fp>(fe_unpack_words<Fp>(yw));
+    out[i] = aff_pack(a);
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_points_from_resident(const AffPacked<C>* __restrict__ in, size_t n, uint32_t* __restrict__ raw) {
+    using Fp = typename C::Fp;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<C> a = aff_unpack(in[i]);
+    uint32_t xw[Fp::NW], yw[Fp::NW];
+    fe_pack_words<Fp>(xw, fe_from_mont<Fp>(a.x));
+    fe_pack_words<Fp>(yw, fe_from_mont<Fp>(a.y));
+    uint32_t* p = raw + i * 2 * Fp::NW;
+    for (int k = 0; k < Fp::NW; k++) { p[k] = xw[k]; p[Fp::NW + k] = yw[k]; }
+}
+
+// ---------------------------------------------------------------------------------------------- batched scalar mul
+// out[i] = k[i] * base[i]  (base == nullptr: the curve generator).  One lane per element, double-and-add.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_scalar_mul(const AffPacked<C>* __restrict__ base, const ScalarWords* __restrict__ k, size_t n,
+                                                       AffPacked<C>* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<C> p = base ? aff_unpack(base[i]) : generator<C>();
+    ScalarWords s = k[i];
+    Xyzz<C> r = xyzz_mul_words<C>(s.w, p);
+    out[i] = aff_pack(xyzz_to_aff<C>(r));
+}
+
+}  // namespace bp

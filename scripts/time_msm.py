@@ -1,0 +1,54 @@
+"""Quick per-stage timing of the MSM device pipeline (development aid; bench.py is the contract)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G
+
+bp = G.load_package()
+
+
+def rand_scalars(ctx, n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x3F            # < 2^254 < r for both curves
+    return a.tobytes()
+
+
+def main():
+    lgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 18, 20]
+    curve = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    cs = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+    ctx = bp.Context(curve, 0)
+    ctx.enable_timing(True)
+    for lg in lgs:
+        n = 1 << lg
+        kv = bp.FieldElementVector.from_bytes(ctx, rand_scalars(ctx, n, 1), n)
+        t0 = time.time()
+        pts = bp.G1Vector.fixed_base(ctx, kv)
+        ctx.synchronize()
+        tgen = time.time() - t0
+        sv = bp.FieldElementVector.from_bytes(ctx, rand_scalars(ctx, n, 2), n)
+        for c in cs:
+            ctx.set_window_bits(c)
+            pts.multi_scalar_mul_var_time(sv)
+            best = None
+            for _ in range(5):
+                t0 = time.time()
+                pts.multi_scalar_mul_var_time(sv)
+                wall = (time.time() - t0) * 1e3
+                tm = ctx.last_timing()
+                if best is None or wall < best[0]:
+                    best = (wall, tm)
+            wall, tm = best
+            print("n=2^%d c=%d gen=%.1fms wall=%.3fms device=%.3fms [count %.3f scan %.3f scatter %.3f tasks %.3f accumulate %.3f reduce %.3f] host_tail~%.3fms  %.3e muls/s" % (
+                lg, c, tgen * 1e3, wall, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], wall - tm[0], n / (wall * 1e-3)), flush=True)
+        pts.free()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""GPU parity tests for the MSM path: the HIP library through its C ABI against the CPU oracle, the committed
+golden vectors, and -- at full size -- the linearity property  MSM(s, k.G) == (<s, k> mod r).G ."""
+import pytest
+
+import __graft_entry__ as G
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bls12_381", "bn254"]
+
+
+def hx(s):
+    return bytes.fromhex(s)
+
+
+@pytest.fixture(scope="module")
+def bp():
+    return G.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctxs(bp):
+    c = {name: bp.Context(cid, 0) for name, cid in bp.CURVE_IDS.items()}
+    yield c
+    for x in c.values():
+        x.close()
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_roundtrip_formats(bp, ctxs, golden, name):
+    ctx = ctxs[name]
+    cases = golden("g1")[name]["add"]
+    pts = b"".join(hx(c["sum"]) for c in cases)     # includes the identity
+    n = len(cases)
+    v = bp.G1Vector.from_bytes(ctx, pts, n)
+    assert len(v) == n
+    assert v.to_bytes() == pts
+    amcl = v.to_bytes(fmt=bp.FMT_AMCL)
+    per = ctx.point_bytes + 1
+    for i in range(n):
+        assert amcl[i * per:(i + 1) * per] == O.g1_to_amcl(ctx.curve, pts[i * ctx.point_bytes:(i + 1) * ctx.point_bytes])
+    v2 = bp.G1Vector.from_bytes(ctx, amcl, n, fmt=bp.FMT_AMCL)
+    assert v2.to_bytes() == pts
+    assert v.to_bytes(offset=3, n=2) == pts[3 * ctx.point_bytes:5 * ctx.point_bytes]
+    with pytest.raises(bp.ValueError_):
+        v.to_bytes(offset=n, n=1)
+    s = O.random_scalars(ctx.curve, 5, 10)
+    f = bp.FieldElementVector.from_bytes(ctx, s, 10)
+    assert f.to_bytes() == s and len(f) == 10
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_golden(bp, ctxs, golden, name):
+    ctx = ctxs[name]
+    for c in golden("msm")[name]:
+        n = c["n"]
+        pts = bp.G1Vector.from_bytes(ctx, b"".join(hx(p) for p in c["points"]), n)
+        sc = bp.FieldElementVector.from_bytes(ctx, b"".join(hx(s) for s in c["scalars"]), n)
+        assert pts.multi_scalar_mul_var_time(sc) == hx(c["out"]), c["name"]
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_every_window_width(bp, ctxs, golden, name):
+    ctx = ctxs[name]
+    cases = [c for c in golden("msm")[name] if c["name"] in ("random_257", "window_edge_scalars", "duplicates_mixed", "r_minus_1")]
+    try:
+        for c in cases:
+            n = c["n"]
+            pts = bp.G1Vector.from_bytes(ctx, b"".join(hx(p) for p in c["points"]), n)
+            sc = bp.FieldElementVector.from_bytes(ctx, b"".join(hx(s) for s in c["scalars"]), n)
+            for bits in range(2, 17):
+                ctx.set_window_bits(bits)
+                assert pts.multi_scalar_mul_var_time(sc) == hx(c["out"]), (c["name"], bits)
+    finally:
+        ctx.set_window_bits(0)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_length_mismatch_is_value_error(bp, ctxs, name):
+    ctx = ctxs[name]
+    g = O.generator(ctx.curve)
+    pts = bp.G1Vector.from_bytes(ctx, g * 4, 4)
+    sc = bp.FieldElementVector.from_ints(ctx, [1, 2, 3])
+    with pytest.raises(bp.ValueError_):           # amcl_wrapper ValueError (ipp.rs:91 .unwrap())
+        pts.multi_scalar_mul_var_time(sc)
+    with pytest.raises(bp.ValueError_):
+        pts.msm_range(2, sc, 0, 3)
+    assert pts.msm_range(1, sc, 0, 3) == O.g1_mul(ctx.curve, (6).to_bytes(32, "little"), g)
+    assert pts.msm_range(0, sc, 0, 0) == bytes(ctx.point_bytes)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_fixed_base_and_scalar_mul(bp, ctxs, name):
+    ctx = ctxs[name]
+    n = 300
+    ks = O.random_scalars(ctx.curve, 21, n)
+    kv = bp.FieldElementVector.from_bytes(ctx, ks, n)
+    pts = bp.G1Vector.fixed_base(ctx, kv)
+    host = pts.to_bytes()
+    assert host == O.fixed_base_batch(ctx.curve, ks, n, nthreads=4)
+    ss = (0).to_bytes(32, "little") + (1).to_bytes(32, "little") + (ctx.r - 1).to_bytes(32, "little") + O.random_scalars(ctx.curve, 22, n - 3)
+    sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+    got = pts.scaled_by(sv).to_bytes()
+    pb = ctx.point_bytes
+    for i in list(range(6)) + [n - 1]:
+        assert got[i * pb:(i + 1) * pb] == O.g1_mul(ctx.curve, ss[i * 32:(i + 1) * 32], host[i * pb:(i + 1) * pb]), i
+
+
+@pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 33, 1000, 4097, 70000])
+def test_msm_random_vs_oracle(bp, ctxs, name, n):
+    ctx = ctxs[name]
+    ks = O.random_scalars(ctx.curve, 100 + n, n)
+    ss = O.random_scalars(ctx.curve, 200 + n, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+    got = pts.multi_scalar_mul_var_time(sv)
+    want = O.msm(ctx.curve, pts.to_bytes(), ss, n, algo=O.PIPPENGER, nthreads=8)
+    assert got == want
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_skewed_scalars(bp, ctxs, name):
+    """config-3-like inputs: bit scalars, all-equal scalars, 1% zeros -- heavy single buckets."""
+    ctx = ctxs[name]
+    n = 20000
+    ks = O.random_scalars(ctx.curve, 31, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    host = pts.to_bytes()
+    import random
+    rnd = random.Random(7)
+    for label, vals in (
+        ("bits", [rnd.getrandbits(1) for _ in range(n)]),
+        ("all_equal", [0x1234567] * n),
+        ("zeros_1pct", [0 if rnd.random() < 0.01 else rnd.getrandbits(250) for _ in range(n)]),
+    ):
+        ss = b"".join(v.to_bytes(32, "little") for v in vals)
+        got = pts.multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, ss, n))
+        assert got == O.msm(ctx.curve, host, ss, n, algo=O.PIPPENGER, nthreads=8), label
+
+
+@pytest.mark.parametrize("name,lg", [("bls12_381", 20), ("bn254", 20), ("bls12_381", 22)])
+def test_msm_full_size_linearity(bp, ctxs, name, lg):
+    """BASELINE sizes (2^20, 2^22): MSM(s, k.G) must equal (<s,k> mod r).G  -- checked with the oracle's Fr inner
+    product and one oracle scalar multiplication; a sample of the device-generated points is checked directly."""
+    ctx = ctxs[name]
+    n = 1 << lg
+    ks = O.random_scalars(ctx.curve, 1000 + lg, n)
+    ss = O.random_scalars(ctx.curve, 2000 + lg, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    pb = ctx.point_bytes
+    gen = O.generator(ctx.curve)
+    for i in (0, 1, n // 2, n - 1):
+        assert pts.to_bytes(offset=i, n=1) == O.g1_mul(ctx.curve, ks[i * 32:(i + 1) * 32], gen)
+    got = pts.multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, ss, n))
+    want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen)
+    assert got == want
+    pts.free()
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_two_stage_sharded_msm(bp, ctxs, name):
+    """The multi-GPU decomposition on one GPU: two index-range shards -> window records -> one finish."""
+    import torch
+    ctx = ctxs[name]
+    n = 6000
+    ks = O.random_scalars(ctx.curve, 41, n)
+    ss = O.random_scalars(ctx.curve, 42, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+    half = n // 2
+    W = bp.msm_window_records(ctx, half)
+    rb = bp.msm_record_bytes(ctx.curve)
+    buf = torch.zeros(2 * W * rb, dtype=torch.uint8, device="cuda:0")
+    bp.msm_windows(ctx, pts, 0, sv, 0, half, buf.data_ptr())
+    bp.msm_windows(ctx, pts, half, sv, half, half, buf.data_ptr() + W * rb)
+    got = bp.msm_finish(ctx, buf.data_ptr(), 2, half)
+    assert got == pts.multi_scalar_mul_var_time(sv)
+    assert got == O.msm(ctx.curve, pts.to_bytes(), ss, n, algo=O.PIPPENGER, nthreads=8)
