@@ -70,6 +70,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     bp = G.load_package()
+    from bulletproofs_amcl_amd import sharding
     curve = bp.CURVE_IDS[args.curve]
     ctx = bp.Context(curve, local_rank)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -88,14 +89,13 @@ def main():
     W = bp.msm_window_records(ctx, n)
     rb = bp.msm_record_bytes(curve)
     mine = torch.zeros(W * rb, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * W * rb, dtype=torch.uint8, device=dev) if world > 1 else mine
 
     def step():
         if world == 1:
             return pts.multi_scalar_mul_var_time(sv)
         bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
-        dist.all_gather_into_tensor(gathered, mine)
-        return bp.msm_finish(ctx, gathered.data_ptr(), world, n)
+        allrec = sharding.all_gather_records(mine, world)          # RCCL all_gather_into_tensor
+        return bp.msm_finish(ctx, allrec.data_ptr(), world, n)
 
     def fence():
         if world > 1:
@@ -139,11 +139,20 @@ def main():
         total_units = world * n
         value = total_units * args.steps / elapsed
         roofline = None
+        traffic, traffic_note = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc_hbm.json")
+        if args.curve == "bls12_381" and args.lg_n == 20 and os.path.exists(pmc):
+            # HBM bytes per k_accumulate launch from the committed rocprofv3 --pmc passes of this same command
+            # (FETCH_SIZE / WRITE_SIZE in KiB; read side doubled per MI355X_MICROARCH.md, uncalibrated for gathers)
+            k = json.load(open(pmc))["kernels"].get("bp::k_accumulate<bp::Bls381>", {})
+            if "FETCH_SIZE_KiB_avg" in k and "WRITE_SIZE_KiB_avg" in k:
+                traffic = int((2 * k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
+                traffic_note = "profiles/r01_bench_n1_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
         if acc_ms:
             avg = float(np.mean(acc_ms)) * 1e-3
             achieved = n * unit_bytes / avg / 1e9
             roofline = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_note,
                         "kernel_ms": round(avg * 1e3, 4), "algorithmic_bytes_per_launch": n * unit_bytes,
                         "pipeline_GBs": round(n * unit_bytes / (float(np.mean(dev_ms)) * 1e-3) / 1e9, 2)}
         out = {

@@ -1,0 +1,32 @@
+"""Index-range sharding of an MSM over the ranks of one node (one process per GPU) and the single exchange step.
+
+MSM is a commutative-monoid sum, so rank g owns the contiguous range [g*n/N, (g+1)*n/N) of points and scalars, runs
+the whole bucket pipeline on it, and contributes W window records; one all_gather (RCCL on GPUs, gloo in the CPU
+tests) replaces the "reduce" -- point addition is not an RCCL reduction op.  No arithmetic here.
+"""
+
+
+def shard_range(n_total, world, rank):
+    """Contiguous [lo, hi) of rank `rank`; sizes differ by at most one; the ranges tile [0, n_total)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_records(mine, world):
+    """Gather every rank's record tensor (uint8, same length on all ranks) into one [world * len] tensor, in rank
+    order.  Uses all_gather_into_tensor where the backend has it (nccl = RCCL), all_gather otherwise (gloo)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return mine
+    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, mine)
+    else:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        out = torch.cat(parts)
+    return out
