@@ -93,6 +93,28 @@ SYMBOLS = {
     "bp_msm_g1_windows": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _P]),
     "bp_msm_g1_finish": (_I, [_P, _P, _SZ, _SZ, _U8P]),
     "bp_msm_last_timing": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
+    "bp_fr_inner_product": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _U8P]),
+    "bp_fr_hadamard": (_I, [_P, _P, _P, _PP]),
+    "bp_fr_scaled_by": (_I, [_P, _P, _U8P, _PP]),
+    "bp_fr_vandermonde": (_I, [_P, _U8P, _SZ, _PP]),
+    "bp_fr_inverse": (_I, [_I, _U8P, _U8P]),
+    "bp_transcript_new": (_I, [_U8P, _SZ, _PP]),
+    "bp_transcript_free": (_I, [_P]),
+    "bp_transcript_append_message": (_I, [_P, _U8P, _SZ, _U8P, _SZ]),
+    "bp_transcript_append_u64": (_I, [_P, _U8P, _SZ, ctypes.c_uint64]),
+    "bp_transcript_challenge_bytes": (_I, [_P, _U8P, _SZ, _U8P, _SZ]),
+    "bp_transcript_commit_point": (_I, [_P, _I, _U8P, _U8P]),
+    "bp_transcript_commit_scalar": (_I, [_P, _I, _U8P, _U8P]),
+    "bp_transcript_challenge_scalar": (_I, [_P, _I, _U8P, _U8P]),
+    "bp_ipp_state_create": (_I, [_P, _P, _P, _U8P, _P, _P, _P, _P, _PP]),
+    "bp_ipp_state_len": (_SZ, [_P]),
+    "bp_ipp_round": (_I, [_P, _U8P, _U8P]),
+    "bp_ipp_fold": (_I, [_P, _U8P, _U8P]),
+    "bp_ipp_state_finish": (_I, [_P, _U8P, _U8P]),
+    "bp_ipp_state_free": (_I, [_P]),
+    "bp_ipp_create": (_I, [_P, _P, _U8P, _P, _P, _P, _P, _P, _P, _U8P, _U8P, ctypes.POINTER(ctypes.c_size_t), _U8P, _U8P]),
+    "bp_ipp_verify": (_I, [_P, _P, _SZ, _P, _P, _U8P, _U8P, _P, _P, _U8P, _U8P, _U8P, _U8P, _SZ]),
+    "bp_ipp_verification_scalars": (_I, [_I, _P, _U8P, _U8P, _SZ, _SZ, _U8P, _U8P, _U8P]),
 }
 
 _lib = None
@@ -326,3 +348,169 @@ def msm_window_records(ctx, n):
 
 def msm_record_bytes(curve):
     return lib().bp_msm_record_bytes(curve)
+
+
+# ---- FieldElementVector helpers -------------------------------------------------------------------------------------
+
+def _fr_inner_product(self, other, aoff=0, boff=0, n=None):
+    """FieldElementVector::inner_product"""
+    if n is None:
+        if len(self) != len(other):
+            raise ValueError_("inner_product: unequal lengths")
+        n = len(self)
+    out = ctypes.create_string_buffer(32)
+    _check(lib().bp_fr_inner_product(self.ctx.h, self.h, aoff, other.h, boff, n, out), "bp_fr_inner_product")
+    return out.raw
+
+
+def _fr_hadamard(self, other):
+    """FieldElementVector::hadamard_product"""
+    h = ctypes.c_void_p()
+    _check(lib().bp_fr_hadamard(self.ctx.h, self.h, other.h, ctypes.byref(h)), "bp_fr_hadamard")
+    return FieldElementVector(self.ctx, h)
+
+
+def _fr_scaled_by(self, s_le32):
+    """FieldElementVector::scaled_by"""
+    h = ctypes.c_void_p()
+    _check(lib().bp_fr_scaled_by(self.ctx.h, self.h, bytes(s_le32), ctypes.byref(h)), "bp_fr_scaled_by")
+    return FieldElementVector(self.ctx, h)
+
+
+def _fr_vandermonde(cls, ctx, e_le32, n):
+    """FieldElementVector::new_vandermonde_vector"""
+    h = ctypes.c_void_p()
+    _check(lib().bp_fr_vandermonde(ctx.h, bytes(e_le32), n, ctypes.byref(h)), "bp_fr_vandermonde")
+    return cls(ctx, h)
+
+
+FieldElementVector.inner_product = _fr_inner_product
+FieldElementVector.hadamard_product = _fr_hadamard
+FieldElementVector.scaled_by = _fr_scaled_by
+FieldElementVector.new_vandermonde_vector = classmethod(_fr_vandermonde)
+
+
+def fr_inverse(curve, x_le32):
+    """FieldElement::inverse (host)"""
+    out = ctypes.create_string_buffer(32)
+    _check(lib().bp_fr_inverse(curve, bytes(x_le32), out), "bp_fr_inverse")
+    return out.raw
+
+
+# ---- transcript (merlin::Transcript + TranscriptProtocol, src/transcript.rs) ---------------------------------------
+
+class Transcript:
+    def __init__(self, label: bytes):
+        self.h = ctypes.c_void_p()
+        _check(lib().bp_transcript_new(label, len(label), ctypes.byref(self.h)), "bp_transcript_new")
+
+    def append_message(self, label, msg):
+        _check(lib().bp_transcript_append_message(self.h, label, len(label), bytes(msg), len(msg)), "append_message")
+
+    def append_u64(self, label, x):
+        _check(lib().bp_transcript_append_u64(self.h, label, len(label), x), "append_u64")
+
+    def challenge_bytes(self, label, n):
+        out = ctypes.create_string_buffer(max(1, n))
+        _check(lib().bp_transcript_challenge_bytes(self.h, label, len(label), out, n), "challenge_bytes")
+        return out.raw[:n]
+
+    def commit_point(self, curve, label, point_le):
+        _check(lib().bp_transcript_commit_point(self.h, curve, label, bytes(point_le)), "commit_point")
+
+    def commit_scalar(self, curve, label, scalar_le32):
+        _check(lib().bp_transcript_commit_scalar(self.h, curve, label, bytes(scalar_le32)), "commit_scalar")
+
+    def challenge_scalar(self, curve, label):
+        out = ctypes.create_string_buffer(32)
+        _check(lib().bp_transcript_challenge_scalar(self.h, curve, label, out), "challenge_scalar")
+        return out.raw
+
+    def free(self):
+        if self.h:
+            lib().bp_transcript_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- inner-product argument (src/ipp.rs) -----------------------------------------------------------------------------
+
+class InnerProductArgumentProof:
+    """src/ipp.rs:13-20: {L: G1Vector, R: G1Vector, a, b}; points as BP_FMT_LE bytes here."""
+
+    def __init__(self, L, R, a, b, lg_n):
+        self.L, self.R, self.a, self.b, self.lg_n = L, R, a, b, lg_n
+
+
+class IPPState:
+    """Device-resident prover state for a host that owns its own transcript (bp_ipp_state_*)."""
+
+    def __init__(self, ctx, G, H, Q_le, G_factors, H_factors, a, b):
+        self.ctx = ctx
+        self.h = ctypes.c_void_p()
+        _check(lib().bp_ipp_state_create(ctx.h, G.h, H.h, bytes(Q_le), G_factors.h, H_factors.h, a.h, b.h, ctypes.byref(self.h)), "bp_ipp_state_create")
+
+    def __len__(self):
+        return lib().bp_ipp_state_len(self.h)
+
+    def round(self):
+        L, R = ctypes.create_string_buffer(self.ctx.point_bytes), ctypes.create_string_buffer(self.ctx.point_bytes)
+        _check(lib().bp_ipp_round(self.h, L, R), "bp_ipp_round")
+        return L.raw, R.raw
+
+    def fold(self, u_le32, u_inv_le32):
+        _check(lib().bp_ipp_fold(self.h, bytes(u_le32), bytes(u_inv_le32)), "bp_ipp_fold")
+
+    def finish(self):
+        a, b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        _check(lib().bp_ipp_state_finish(self.h, a, b), "bp_ipp_state_finish")
+        return a.raw, b.raw
+
+    def free(self):
+        if self.h:
+            lib().bp_ipp_state_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class IPP:
+    """IPP::create_ipp / verify_ipp / verification_scalars (src/ipp.rs:22-316)."""
+
+    @staticmethod
+    def create_ipp(ctx, transcript, Q_le, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec):
+        n = len(G_vec)
+        lg = max(1, n.bit_length())
+        L = ctypes.create_string_buffer(lg * ctx.point_bytes)
+        R = ctypes.create_string_buffer(lg * ctx.point_bytes)
+        a, b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        lg_n = ctypes.c_size_t(0)
+        _check(lib().bp_ipp_create(ctx.h, transcript.h, bytes(Q_le), G_factors.h, H_factors.h, G_vec.h, H_vec.h, a_vec.h, b_vec.h, L, R,
+                                   ctypes.byref(lg_n), a, b), "bp_ipp_create")
+        k = lg_n.value
+        return InnerProductArgumentProof(L.raw[: k * ctx.point_bytes], R.raw[: k * ctx.point_bytes], a.raw, b.raw, k)
+
+    @staticmethod
+    def verify_ipp(ctx, n, transcript, G_factors, H_factors, P_le, Q_le, G, H, a_le32, b_le32, L_le, R_le):
+        """Returns None on success, raises VerificationError otherwise (Result<(), R1CSError>)."""
+        lg_n = len(L_le) // ctx.point_bytes
+        _check(lib().bp_ipp_verify(ctx.h, transcript.h, n, G_factors.h, H_factors.h, bytes(P_le), bytes(Q_le), G.h, H.h, bytes(a_le32),
+                                   bytes(b_le32), bytes(L_le), bytes(R_le), lg_n), "bp_ipp_verify")
+
+    @staticmethod
+    def verification_scalars(curve, L_le, R_le, n, transcript):
+        pb = 2 * curve_info(curve).fp_bytes
+        lg_n = len(L_le) // pb
+        us, uis, s = (ctypes.create_string_buffer(max(1, lg_n) * 32), ctypes.create_string_buffer(max(1, lg_n) * 32),
+                      ctypes.create_string_buffer(max(1, n) * 32))
+        _check(lib().bp_ipp_verification_scalars(curve, transcript.h, bytes(L_le), bytes(R_le), lg_n, n, us, uis, s), "bp_ipp_verification_scalars")
+        return us.raw[: lg_n * 32], uis.raw[: lg_n * 32], s.raw[: n * 32]

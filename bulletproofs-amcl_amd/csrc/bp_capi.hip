@@ -1,81 +1,11 @@
 // bp_capi.hip -- implementation of the C ABI in include/bpmsm.h (libbpmsm.so).
 // Host orchestration of the gfx950 kernels in bp_kernels.cuh; no CPU fallback for any compute entry point.
-#include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <new>
 #include <vector>
 
-#include "../../include/bpmsm.h"
-#include "bp_kernels.cuh"
+#include "bp_internal.hpp"
 
 using namespace bp;
-
-#define HIPCHK(expr)                                                                                         \
-    do {                                                                                                     \
-        hipError_t e_ = (expr);                                                                              \
-        if (e_ != hipSuccess) {                                                                              \
-            if (getenv("BP_VERBOSE")) fprintf(stderr, "[bpmsm] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return BP_ERR_DEVICE;                                                                            \
-        }                                                                                                    \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------ handles
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return BP_OK;
-        if (p) { if (hipFree(p) != hipSuccess) return BP_ERR_DEVICE; p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return BP_ERR_DEVICE; }
-        cap = want;
-        return BP_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct bp_ctx {
-    int curve = 0;
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    int c_override = 0;
-    bool timing = false;
-    // MSM workspace
-    DevBuf count, cursor, block_sums, idx, code, ntasks, task_off, order, t_start, t_len, tsum, heavy, meta, partial, window_sum, scratch;
-    void* host_pinned = nullptr;
-    size_t host_pinned_cap = 0;
-    hipEvent_t ev[8] = {};
-    bool ev_ready = false;
-    float last_ms[8] = {};
-    int last_ms_n = 0;
-};
-
-struct bp_g1vec {
-    bp_ctx* ctx;
-    void* d;
-    size_t n;
-    bool owned;
-};
-struct bp_frvec {
-    bp_ctx* ctx;
-    void* d;
-    size_t n;
-    bool owned;
-};
-
-static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
-static inline bool curve_ok(int curve) { return curve == BP_CURVE_BLS12_381 || curve == BP_CURVE_BN254; }
-
-static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->host_pinned_cap) return BP_OK;
-    if (ctx->host_pinned) { HIPCHK(hipHostFree(ctx->host_pinned)); ctx->host_pinned = nullptr; ctx->host_pinned_cap = 0; }
-    HIPCHK(hipHostMalloc(&ctx->host_pinned, bytes + 4096, hipHostMallocDefault));
-    ctx->host_pinned_cap = bytes + 4096;
-    return BP_OK;
-}
 
 // ------------------------------------------------------------------------------------------------ geometry
 struct MsmGeom {
@@ -155,6 +85,7 @@ struct Impl {
         msm_geom(g, C::Fr::BITS, n, ctx->c_override);
         const WinTab& tab = g.tab;
         const int W = tab.W;
+        if (getenv("BP_TRACE")) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d nbuckets=%u m=%u bpw=%u\n", n, g.c, W, tab.nbuckets, g.m, g.bpw);
         if (n >= ((size_t)1 << 31)) return BP_ERR_ARG;                      // the sign lives in bit 31 of an index
         if ((uint64_t)W * n >= ((uint64_t)1 << 32)) return BP_ERR_ARG;      // 32-bit slot offsets
         hipStream_t st = ctx->stream;
@@ -207,30 +138,45 @@ struct Impl {
         unsigned sgrid = (unsigned)((n + kBlock - 1) / kBlock);
         if (sgrid > 256 * 16) sgrid = 256 * 16;
         hipLaunchKernelGGL(k_digits_count, dim3(sgrid), dim3(kBlock), 0, st, sc, n, tab, code, count);
+        BP_TRACE_SYNC(ctx, "k_digits_count");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, count, nb, bsum);
+        BP_TRACE_SYNC(ctx, "k_scan_block_sums");
         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, bsum, scan_blocks);
+        BP_TRACE_SYNC(ctx, "k_scan_top");
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, count, nb, bsum, count, cursor);
+        BP_TRACE_SYNC(ctx, "k_scan_apply");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
         unsigned tgrid = (unsigned)((n + kBlock - 1) / kBlock);
         if (tgrid > 1024) tgrid = 1024;
         hipLaunchKernelGGL(k_digits_scatter, dim3(tgrid, W), dim3(kBlock), 0, st, code, n, tab, cursor, idx);
+        BP_TRACE_SYNC(ctx, "k_digits_scatter");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[3], st));
         // count[] = bucket starts, cursor[] = bucket ends.  Tasks:
         unsigned bgrid = (unsigned)((nb + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, ntasks, bins);
+        BP_TRACE_SYNC(ctx, "k_task_count");
         hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, st, bins, total_tasks);
+        BP_TRACE_SYNC(ctx, "k_task_bins_scan");
         hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum);
+        BP_TRACE_SYNC(ctx, "k_scan_block_sums");
         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, bsum, scan_blocks);
+        BP_TRACE_SYNC(ctx, "k_scan_top");
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum, task_off, (uint32_t*)nullptr);
+        BP_TRACE_SYNC(ctx, "k_scan_apply");
         hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len, heavy, nheavy);
+        BP_TRACE_SYNC(ctx, "k_task_emit");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));
         hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((max_tasks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pts, idx, order, t_start, t_len,
                            total_tasks, tsum);
+        BP_TRACE_SYNC(ctx, "k_accumulate<C>");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
         hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)max_heavy), dim3(64), 0, st, heavy, nheavy, task_off, ntasks, tsum);
+        BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
         hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(g.bpw, W), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
+        BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
         hipLaunchKernelGGL(k_window_sums<C>, dim3(W), dim3(kBlock), 0, st, partial, g.bpw, wsum);
+        BP_TRACE_SYNC(ctx, "k_window_sums<C>");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
         HIPCHK(hipGetLastError());
         return BP_OK;
@@ -346,6 +292,11 @@ struct Impl {
 static int set_device(const bp_ctx* ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     return BP_OK;
+}
+int bp_internal_set_device(const bp_ctx* ctx) { return set_device(ctx); }
+
+int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le) {
+    DISPATCH(ctx, I::msm(ctx, points, 0, scalars, 0, n, out_le));
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI

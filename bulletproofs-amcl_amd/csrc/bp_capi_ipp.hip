@@ -1,0 +1,484 @@
+// bp_capi_ipp.hip -- C ABI (include/bpmsm.h) for the FieldElementVector helpers, the host transcript and the
+// inner-product argument.  Host orchestration mirrors /root/reference src/ipp.rs:35-315 and src/transcript.rs:29-61;
+// all per-element work runs in the kernels of bp_ipp.cuh, the MSMs in the bucket pipeline of bp_capi.hip.
+#include <new>
+#include <vector>
+
+#include "bp_internal.hpp"
+#include "bp_ipp.cuh"
+#include "bp_merlin.hpp"
+
+using namespace bp;
+
+struct bp_transcript {
+    Transcript t;
+    bp_transcript(const uint8_t* label, size_t len) : t(label, len) {}
+};
+
+struct bp_ipp_state {
+    bp_ctx* ctx;
+    size_t n0, n;            // original / current length
+    bool first;              // G_factors / H_factors still to be applied (src/ipp.rs:68-136)
+    void *G, *H, *a, *b;     // working copies (src/ipp.rs:57-60)
+    void *gf, *hf;           // factors (first round only)
+    void *Q;                 // one resident point
+    void *pts_tmp, *sc_tmp;  // MSM terms of L and R
+    void *cLR;               // c_L, c_R
+    void *partial;           // inner-product block partials
+};
+
+namespace {
+
+constexpr unsigned kInnerBlocks = 256;
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// ---- host-side Fr helpers (shared templates, host build) ----------------------------------------------------
+template <class F> Fe<F> fr_from_le(const uint8_t* le32) {
+    uint32_t w[8];
+    memcpy(w, le32, 32);
+    return fe_to_mont<F>(fe_unpack_words<F>(w));
+}
+template <class F> void fr_to_le(const Fe<F>& x_mont, uint8_t* le32) {
+    uint32_t w[8];
+    fe_pack_words<F>(w, fe_from_mont<F>(x_mont));
+    memcpy(le32, w, 32);
+}
+template <class F> ScalarWords fr_mont_words(const Fe<F>& x_mont) {
+    ScalarWords s;
+    fe_pack_words<F>(s.w, x_mont);
+    return s;
+}
+// FieldElement::from(&[u8; MODBYTES]): big-endian integer mod r (src/transcript.rs:55-60)  [UNVERIFIED-RECALL]
+template <class F> Fe<F> fr_from_be_reduce(const uint8_t* be, int nbytes) {
+    Fe<F> acc = fe_zero<F>();
+    Fe<F> c256 = fe_zero<F>();
+    c256.v[0] = 256;
+    c256 = fe_to_mont<F>(c256);
+    for (int i = 0; i < nbytes; i++) {
+        Fe<F> d = fe_zero<F>();
+        d.v[0] = be[i];
+        acc = fe_add(fe_mul(acc, c256), fe_to_mont<F>(d));
+    }
+    return acc;
+}
+
+// amcl byte formats used by the transcript ([UNVERIFIED-RECALL])
+void point_le_to_amcl(const uint8_t* le, int fb, uint8_t* out /* 2 fb + 1 */) {
+    memset(out, 0, 2 * fb + 1);
+    out[0] = 0x04;
+    bool z = true;
+    for (int k = 0; k < 2 * fb; k++) if (le[k]) { z = false; break; }
+    if (z) { out[2 * fb] = 1; return; }
+    for (int k = 0; k < fb; k++) { out[fb - k] = le[k]; out[2 * fb - k] = le[fb + k]; }
+}
+
+template <class C>
+struct Ipp {
+    using F = typename C::Fr;
+    using Fp = typename C::Fp;
+    static constexpr size_t kPt = sizeof(AffPacked<C>);
+    static constexpr int kFb = 4 * Fp::NW;
+
+    static int inner(bp_ctx* ctx, const ScalarWords* a, const ScalarWords* b, size_t n, ScalarWords* d_partial, ScalarWords* d_out) {
+        unsigned g = blocks_for(n);
+        if (g > kInnerBlocks) g = kInnerBlocks;
+        if (g == 0) g = 1;
+        hipLaunchKernelGGL(k_fr_inner<C>, dim3(g), dim3(kBlock), 0, ctx->stream, a, b, n, d_partial);
+        hipLaunchKernelGGL(k_fr_inner_final<C>, dim3(1), dim3(kBlock), 0, ctx->stream, d_partial, g, d_out);
+        HIPCHK(hipGetLastError());
+        return BP_OK;
+    }
+
+    static int round(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
+        bp_ctx* ctx = st->ctx;
+        size_t h = st->n / 2;
+        auto* a = (ScalarWords*)st->a; auto* b = (ScalarWords*)st->b;
+        auto* cLR = (ScalarWords*)st->cLR;
+        int rc;
+        if ((rc = inner(ctx, a, b + h, h, (ScalarWords*)st->partial, cLR))) return rc;          // c_L = <a_L, b_R>
+        if ((rc = inner(ctx, a + h, b, h, (ScalarWords*)st->partial, cLR + 1))) return rc;      // c_R = <a_R, b_L>
+        hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
+                           (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,
+                           st->first ? (const ScalarWords*)st->hf : nullptr, (const AffPacked<C>*)st->Q, cLR, h, (AffPacked<C>*)st->pts_tmp,
+                           (ScalarWords*)st->sc_tmp);
+        HIPCHK(hipGetLastError());
+        BP_TRACE_SYNC(ctx, "ipp inner+pack");
+        size_t blk = 2 * h + 1;
+        if ((rc = bp_internal_msm(ctx, st->pts_tmp, st->sc_tmp, blk, L_le))) return rc;
+        if ((rc = bp_internal_msm(ctx, (const uint8_t*)st->pts_tmp + blk * kPt, (const uint8_t*)st->sc_tmp + blk * 32, blk, R_le))) return rc;
+        return BP_OK;
+    }
+
+    static int fold(bp_ipp_state* st, const uint8_t* u_le, const uint8_t* uinv_le) {
+        bp_ctx* ctx = st->ctx;
+        size_t h = st->n / 2;
+        Fe<F> u = fr_from_le<F>(u_le), ui = fr_from_le<F>(uinv_le);
+        BP_TRACE_SYNC(ctx, "ipp fold: launching");
+        hipLaunchKernelGGL(k_ipp_fold<C>, dim3(blocks_for(2 * h)), dim3(kBlock), 0, ctx->stream, (AffPacked<C>*)st->G, (AffPacked<C>*)st->H,
+                           (ScalarWords*)st->a, (ScalarWords*)st->b, st->first ? (const ScalarWords*)st->gf : nullptr,
+                           st->first ? (const ScalarWords*)st->hf : nullptr, fr_mont_words<F>(u), fr_mont_words<F>(ui), h);
+        HIPCHK(hipGetLastError());
+        BP_TRACE_SYNC(ctx, "ipp fold");
+        st->n = h;
+        st->first = false;
+        return BP_OK;
+    }
+
+    // ---- transcript protocol (src/transcript.rs:29-61) ----
+    static void commit_point(Transcript& t, const char* label, const uint8_t* p_le) {
+        uint8_t buf[2 * kFb + 1];
+        point_le_to_amcl(p_le, kFb, buf);
+        t.append_message((const uint8_t*)label, strlen(label), buf, sizeof buf);
+    }
+    static void commit_scalar(Transcript& t, const char* label, const uint8_t* s_le) {
+        uint8_t buf[C::MODBYTES];
+        memset(buf, 0, sizeof buf);
+        for (int k = 0; k < 32; k++) buf[C::MODBYTES - 1 - k] = s_le[k];     // MODBYTES big-endian
+        t.append_message((const uint8_t*)label, strlen(label), buf, sizeof buf);
+    }
+    static Fe<F> challenge_scalar(Transcript& t, const char* label) {
+        uint8_t buf[C::MODBYTES];
+        t.challenge_bytes((const uint8_t*)label, strlen(label), buf, sizeof buf);
+        return fr_from_be_reduce<F>(buf, C::MODBYTES);
+    }
+    static void ipp_domain_sep(Transcript& t, uint64_t n) {
+        t.append_message((const uint8_t*)"dom-sep", 7, (const uint8_t*)"ipp v1", 6);
+        t.append_u64((const uint8_t*)"n", 1, n);
+    }
+
+    // IPP::create_ipp, src/ipp.rs:35-202
+    static int create(bp_ipp_state* st, Transcript& t, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out, uint8_t* b_out) {
+        ipp_domain_sep(t, st->n);                                                       // :62
+        size_t k = 0;
+        int rc;
+        while (st->n != 1) {                                                            // :68, :138
+            uint8_t* L = L_out + k * 2 * kFb;
+            uint8_t* R = R_out + k * 2 * kFb;
+            if ((rc = round(st, L, R))) return rc;                                      // :77-104 / :145-170
+            commit_point(t, "L", L);                                                    // :106-107 / :172-173
+            commit_point(t, "R", R);
+            Fe<F> u = challenge_scalar(t, "u");                                         // :112 / :178
+            Fe<F> ui = fe_inv<F>(u);                                                    // :113 / :179
+            uint8_t ub[32], uib[32];
+            fr_to_le<F>(u, ub); fr_to_le<F>(ui, uib);
+            if ((rc = fold(st, ub, uib))) return rc;                                    // :115-130 / :181-188
+            k++;
+        }
+        if (lg_n_out) *lg_n_out = k;
+        HIPCHK(hipMemcpyAsync(a_out, st->a, 32, hipMemcpyDeviceToHost, st->ctx->stream));   // :196-201
+        HIPCHK(hipMemcpyAsync(b_out, st->b, 32, hipMemcpyDeviceToHost, st->ctx->stream));
+        HIPCHK(hipStreamSynchronize(st->ctx->stream));
+        return BP_OK;
+    }
+
+    // IPP::verification_scalars, src/ipp.rs:262-315 (host: O(lg n) transcript work + O(n) Fr products)
+    static int verification_scalars(Transcript& t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, std::vector<Fe<F>>& ch,
+                                    std::vector<Fe<F>>& ch_inv) {
+        if (lg_n >= 32) return BP_ERR_VERIFY;                                           // :269-273
+        if (n != ((size_t)1 << lg_n)) return BP_ERR_VERIFY;                             // :274-276
+        ipp_domain_sep(t, n);                                                           // :278
+        ch.resize(lg_n); ch_inv.resize(lg_n);
+        for (size_t j = 0; j < lg_n; j++) {                                             // :283-288
+            commit_point(t, "L", L_le + j * 2 * kFb);
+            commit_point(t, "R", R_le + j * 2 * kFb);
+            ch[j] = challenge_scalar(t, "u");
+            ch_inv[j] = fe_inv<F>(ch[j]);                                               // batch_invert :295 (same values)
+        }
+        return BP_OK;
+    }
+
+    // IPP::verify_ipp, src/ipp.rs:204-260
+    static int verify(bp_ctx* ctx, Transcript& t, size_t n, const bp_frvec* Gf, const bp_frvec* Hf, const uint8_t* P_le, const uint8_t* Q_le,
+                      const bp_g1vec* G, const bp_g1vec* H, const uint8_t* a_le, const uint8_t* b_le, const uint8_t* L_le, const uint8_t* R_le,
+                      size_t lg_n) {
+        std::vector<Fe<F>> ch, ch_inv;
+        int rc = verification_scalars(t, L_le, R_le, lg_n, n, ch, ch_inv);              // :218
+        if (rc) return rc;
+        size_t m = 1 + 2 * n + 2 * lg_n;
+        void *pts = nullptr, *sc = nullptr, *chd = nullptr, *raw = nullptr;
+        auto cleanup = [&]() { if (pts) (void)hipFree(pts); if (sc) (void)hipFree(sc); if (chd) (void)hipFree(chd); if (raw) (void)hipFree(raw); };
+        if (hipMalloc(&pts, m * kPt) != hipSuccess || hipMalloc(&sc, m * 32) != hipSuccess || hipMalloc(&chd, (2 * lg_n + 1) * 32) != hipSuccess ||
+            hipMalloc(&raw, (2 * lg_n + 1) * 2 * kFb) != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+        // challenges (Montgomery form) for the per-element products
+        std::vector<ScalarWords> hch(2 * lg_n + 1);
+        for (size_t j = 0; j < lg_n; j++) { hch[j] = fr_mont_words<F>(ch[j]); hch[lg_n + j] = fr_mont_words<F>(ch_inv[j]); }
+        Fe<F> a = fr_from_le<F>(a_le), b = fr_from_le<F>(b_le);
+        // head and tail scalars: a*b, -u_j^2, -u_j^-2 (canonical)                      :234-242
+        std::vector<ScalarWords> ends(1 + 2 * lg_n);
+        { uint32_t w[8]; fe_pack_words<F>(w, fe_from_mont<F>(fe_mul(a, b))); memcpy(ends[0].w, w, 32); }
+        for (size_t j = 0; j < lg_n; j++) {
+            uint32_t w[8];
+            fe_pack_words<F>(w, fe_from_mont<F>(fe_neg(fe_sqr(ch[j])))); memcpy(ends[1 + j].w, w, 32);
+            fe_pack_words<F>(w, fe_from_mont<F>(fe_neg(fe_sqr(ch_inv[j])))); memcpy(ends[1 + lg_n + j].w, w, 32);
+        }
+        // points Q, L_vec, R_vec -> resident form                                       :244-249
+        std::vector<uint8_t> hraw((2 * lg_n + 1) * 2 * kFb);
+        memcpy(hraw.data(), Q_le, 2 * kFb);
+        if (lg_n) { memcpy(hraw.data() + 2 * kFb, L_le, lg_n * 2 * kFb); memcpy(hraw.data() + (1 + lg_n) * 2 * kFb, R_le, lg_n * 2 * kFb); }
+        hipStream_t s = ctx->stream;
+        bool ok = hipMemcpyAsync(chd, hch.data(), 2 * lg_n * 32 + 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(sc, ends.data(), 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  (lg_n == 0 || hipMemcpyAsync((uint8_t*)sc + (1 + 2 * n) * 32, ends.data() + 1, 2 * lg_n * 32, hipMemcpyHostToDevice, s) == hipSuccess);
+        if (!ok) { cleanup(); return BP_ERR_DEVICE; }
+        // Q -> pts[0]; L,R -> pts[1+2n ..]
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)raw, (size_t)1, (AffPacked<C>*)pts);
+        if (lg_n)
+            hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(2 * lg_n)), dim3(kBlock), 0, s, (const uint32_t*)((uint8_t*)raw + 2 * kFb),
+                               2 * lg_n, (AffPacked<C>*)pts + 1 + 2 * n);
+        hipLaunchKernelGGL(k_ipp_verify_terms<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
+                           (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, (const ScalarWords*)chd, (const ScalarWords*)chd + lg_n, (int)lg_n,
+                           fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)pts, (ScalarWords*)sc);
+        if (hipGetLastError() != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+        uint8_t expect[2 * kFb];
+        rc = bp_internal_msm(ctx, pts, sc, m, expect);                                  // :251-253
+        if (hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : BP_ERR_DEVICE;
+        cleanup();
+        if (rc) return rc;
+        return memcmp(expect, P_le, 2 * kFb) == 0 ? BP_OK : BP_ERR_VERIFY;              // :255-259
+    }
+};
+
+#define IPP_DISPATCH(curve_, expr)                                         \
+    do {                                                                   \
+        if ((curve_) == BP_CURVE_BLS12_381) { using I = Ipp<Bls381>; return expr; } \
+        else { using I = Ipp<Bn254>; return expr; }                        \
+    } while (0)
+
+int alloc_frvec(bp_ctx* ctx, size_t n, bp_frvec** out) { return bp_frvec_alloc(ctx, n, out); }
+
+}  // namespace
+
+extern "C" {
+
+// ---- transcript ---------------------------------------------------------------------------------------------
+int bp_transcript_new(const uint8_t* label, size_t label_len, bp_transcript** out) {
+    if (!out || (!label && label_len)) return BP_ERR_ARG;
+    *out = new (std::nothrow) bp_transcript(label, label_len);
+    return *out ? BP_OK : BP_ERR_DEVICE;
+}
+int bp_transcript_free(bp_transcript* t) { delete t; return BP_OK; }
+int bp_transcript_append_message(bp_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len) {
+    if (!t) return BP_ERR_ARG;
+    t->t.append_message(label, label_len, msg, msg_len);
+    return BP_OK;
+}
+int bp_transcript_append_u64(bp_transcript* t, const uint8_t* label, size_t label_len, uint64_t x) {
+    if (!t) return BP_ERR_ARG;
+    t->t.append_u64(label, label_len, x);
+    return BP_OK;
+}
+int bp_transcript_challenge_bytes(bp_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len) {
+    if (!t || (!out && out_len)) return BP_ERR_ARG;
+    t->t.challenge_bytes(label, label_len, out, out_len);
+    return BP_OK;
+}
+int bp_transcript_commit_point(bp_transcript* t, int curve_id, const char* label, const uint8_t* point_le) {
+    if (!t || !curve_ok(curve_id) || !label || !point_le) return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_point(t->t, label, point_le); else Ipp<Bn254>::commit_point(t->t, label, point_le);
+    return BP_OK;
+}
+int bp_transcript_commit_scalar(bp_transcript* t, int curve_id, const char* label, const uint8_t* scalar_le32) {
+    if (!t || !curve_ok(curve_id) || !label || !scalar_le32) return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_scalar(t->t, label, scalar_le32); else Ipp<Bn254>::commit_scalar(t->t, label, scalar_le32);
+    return BP_OK;
+}
+int bp_transcript_challenge_scalar(bp_transcript* t, int curve_id, const char* label, uint8_t* out_le32) {
+    if (!t || !curve_ok(curve_id) || !label || !out_le32) return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) fr_to_le<Bls381Fr>(Ipp<Bls381>::challenge_scalar(t->t, label), out_le32);
+    else fr_to_le<Bn254Fr>(Ipp<Bn254>::challenge_scalar(t->t, label), out_le32);
+    return BP_OK;
+}
+
+// ---- host Fr helpers ----------------------------------------------------------------------------------------
+int bp_fr_inverse(int curve_id, const uint8_t* in_le32, uint8_t* out_le32) {
+    if (!curve_ok(curve_id) || !in_le32 || !out_le32) return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) fr_to_le<Bls381Fr>(fe_inv<Bls381Fr>(fr_from_le<Bls381Fr>(in_le32)), out_le32);
+    else fr_to_le<Bn254Fr>(fe_inv<Bn254Fr>(fr_from_le<Bn254Fr>(in_le32)), out_le32);
+    return BP_OK;
+}
+
+// ---- FieldElementVector kernels -----------------------------------------------------------------------------
+int bp_fr_inner_product(bp_ctx* ctx, const bp_frvec* a, size_t aoff, const bp_frvec* b, size_t boff, size_t n, uint8_t* out_le32) {
+    if (!ctx || !a || !b || !out_le32) return BP_ERR_ARG;
+    if (aoff > a->n || n > a->n - aoff || boff > b->n || n > b->n - boff) return BP_ERR_LENGTH;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    if ((rc = ctx->scratch.reserve((kInnerBlocks + 2) * 32))) return rc;
+    auto* part = (ScalarWords*)ctx->scratch.p;
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = Ipp<Bls381>::inner(ctx, (const ScalarWords*)a->d + aoff, (const ScalarWords*)b->d + boff, n, part + 1, part);
+    else rc = Ipp<Bn254>::inner(ctx, (const ScalarWords*)a->d + aoff, (const ScalarWords*)b->d + boff, n, part + 1, part);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out_le32, part, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+
+int bp_fr_hadamard(bp_ctx* ctx, const bp_frvec* a, const bp_frvec* b, bp_frvec** out) {
+    if (!ctx || !a || !b || !out) return BP_ERR_ARG;
+    if (a->n != b->n) return BP_ERR_LENGTH;
+    int rc = alloc_frvec(ctx, a->n, out); if (rc) return rc;
+    if (a->n == 0) return BP_OK;
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_fr_hadamard<Bls381>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, (const ScalarWords*)b->d, a->n, (ScalarWords*)(*out)->d);
+    else
+        hipLaunchKernelGGL(k_fr_hadamard<Bn254>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, (const ScalarWords*)b->d, a->n, (ScalarWords*)(*out)->d);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_frvec** out) {
+    if (!ctx || !a || !s_le32 || !out) return BP_ERR_ARG;
+    int rc = alloc_frvec(ctx, a->n, out); if (rc) return rc;
+    if (a->n == 0) return BP_OK;
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_fr_scale<Bls381>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, fr_mont_words<Bls381Fr>(fr_from_le<Bls381Fr>(s_le32)), a->n, (ScalarWords*)(*out)->d);
+    else
+        hipLaunchKernelGGL(k_fr_scale<Bn254>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(s_le32)), a->n, (ScalarWords*)(*out)->d);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** out) {
+    if (!ctx || !e_le32 || !out) return BP_ERR_ARG;
+    int rc = alloc_frvec(ctx, n, out); if (rc) return rc;
+    if (n == 0) return BP_OK;
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_fr_vandermonde<Bls381>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, fr_mont_words<Bls381Fr>(fr_from_le<Bls381Fr>(e_le32)), n, (ScalarWords*)(*out)->d);
+    else
+        hipLaunchKernelGGL(k_fr_vandermonde<Bn254>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(e_le32)), n, (ScalarWords*)(*out)->d);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+// ---- IPP device-resident state ------------------------------------------------------------------------------
+int bp_ipp_state_free(bp_ipp_state* st) {
+    if (!st) return BP_OK;
+    (void)hipSetDevice(st->ctx->device);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    for (void* p : {st->G, st->H, st->a, st->b, st->gf, st->hf, st->Q, st->pts_tmp, st->sc_tmp, st->cLR, st->partial}) if (p) (void)hipFree(p);
+    delete st;
+    return BP_OK;
+}
+
+int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* Q_le, const bp_frvec* Gf, const bp_frvec* Hf,
+                        const bp_frvec* a, const bp_frvec* b, bp_ipp_state** out) {
+    if (!ctx || !G || !H || !Q_le || !Gf || !Hf || !a || !b || !out) return BP_ERR_ARG;
+    *out = nullptr;
+    size_t n = G->n;
+    if (n == 0 || (n & (n - 1))) return BP_ERR_ARG;                                                  // assert!(n.is_power_of_two())  ipp.rs:48
+    if (H->n != n || a->n != n || b->n != n || Gf->n != n || Hf->n != n) return BP_ERR_ARG;          // assert_eq! lengths            ipp.rs:51-55
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    size_t pt = 2 * (size_t)fp_bytes_of(ctx->curve);
+    bp_ipp_state* st = new (std::nothrow) bp_ipp_state();
+    if (!st) return BP_ERR_DEVICE;
+    memset(st, 0, sizeof *st);
+    st->ctx = ctx; st->n0 = st->n = n; st->first = true;
+    size_t blk = n + 1;   // 2h + 1 terms per MSM, two MSMs
+    bool ok = hipMalloc(&st->G, n * pt) == hipSuccess && hipMalloc(&st->H, n * pt) == hipSuccess && hipMalloc(&st->a, n * 32) == hipSuccess &&
+              hipMalloc(&st->b, n * 32) == hipSuccess && hipMalloc(&st->gf, n * 32) == hipSuccess && hipMalloc(&st->hf, n * 32) == hipSuccess &&
+              hipMalloc(&st->Q, pt) == hipSuccess && hipMalloc(&st->pts_tmp, 2 * blk * pt) == hipSuccess &&
+              hipMalloc(&st->sc_tmp, 2 * blk * 32) == hipSuccess && hipMalloc(&st->cLR, 64) == hipSuccess &&
+              hipMalloc(&st->partial, (kInnerBlocks + 1) * 32) == hipSuccess;
+    hipStream_t s = ctx->stream;
+    ok = ok && hipMemcpyAsync(st->G, G->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&                       // clones, ipp.rs:57-60
+         hipMemcpyAsync(st->H, H->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(st->a, a->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(st->b, b->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(st->gf, Gf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(st->hf, Hf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (ok) {
+        // Q: host bytes -> resident form (reuse pts_tmp as the raw staging area)
+        ok = hipMemcpyAsync(st->pts_tmp, Q_le, pt, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (ok) {
+            if (ctx->curve == BP_CURVE_BLS12_381)
+                hipLaunchKernelGGL(k_points_to_resident<Bls381>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)st->pts_tmp, (size_t)1, (AffPacked<Bls381>*)st->Q);
+            else
+                hipLaunchKernelGGL(k_points_to_resident<Bn254>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)st->pts_tmp, (size_t)1, (AffPacked<Bn254>*)st->Q);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        }
+    }
+    if (!ok) { bp_ipp_state_free(st); return BP_ERR_DEVICE; }
+    *out = st;
+    return BP_OK;
+}
+
+size_t bp_ipp_state_len(const bp_ipp_state* st) { return st ? st->n : 0; }
+
+int bp_ipp_round(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
+    if (!st || !L_le || !R_le || st->n < 2) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(st->ctx); if (rc) return rc;
+    IPP_DISPATCH(st->ctx->curve, I::round(st, L_le, R_le));
+}
+
+int bp_ipp_fold(bp_ipp_state* st, const uint8_t* u_le32, const uint8_t* u_inv_le32) {
+    if (!st || !u_le32 || !u_inv_le32 || st->n < 2) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(st->ctx); if (rc) return rc;
+    IPP_DISPATCH(st->ctx->curve, I::fold(st, u_le32, u_inv_le32));
+}
+
+int bp_ipp_state_finish(bp_ipp_state* st, uint8_t* a_le32, uint8_t* b_le32) {
+    if (!st || !a_le32 || !b_le32 || st->n != 1) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(st->ctx); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(a_le32, st->a, 32, hipMemcpyDeviceToHost, st->ctx->stream));
+    HIPCHK(hipMemcpyAsync(b_le32, st->b, 32, hipMemcpyDeviceToHost, st->ctx->stream));
+    HIPCHK(hipStreamSynchronize(st->ctx->stream));
+    return BP_OK;
+}
+
+// ---- IPP::create_ipp / verify_ipp with the library's host transcript ----------------------------------------
+int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
+                  const bp_g1vec* H, const bp_frvec* a, const bp_frvec* b, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out_le32,
+                  uint8_t* b_out_le32) {
+    if (!t || !a_out_le32 || !b_out_le32) return BP_ERR_ARG;
+    bp_ipp_state* st = nullptr;
+    int rc = bp_ipp_state_create(ctx, G, H, Q_le, G_factors, H_factors, a, b, &st);
+    if (rc) return rc;
+    if (st->n > 1 && (!L_out || !R_out)) { bp_ipp_state_free(st); return BP_ERR_ARG; }
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = Ipp<Bls381>::create(st, t->t, L_out, R_out, lg_n_out, a_out_le32, b_out_le32);
+    else rc = Ipp<Bn254>::create(st, t->t, L_out, R_out, lg_n_out, a_out_le32, b_out_le32);
+    bp_ipp_state_free(st);
+    return rc;
+}
+
+int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_factors, const bp_frvec* H_factors, const uint8_t* P_le,
+                  const uint8_t* Q_le, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* a_le32, const uint8_t* b_le32, const uint8_t* L_le,
+                  const uint8_t* R_le, size_t lg_n) {
+    if (!ctx || !t || !G_factors || !H_factors || !P_le || !Q_le || !G || !H || !a_le32 || !b_le32 || (lg_n && (!L_le || !R_le))) return BP_ERR_ARG;
+    if (lg_n >= 32 || n != ((size_t)1 << lg_n)) return BP_ERR_VERIFY;           // verification_scalars, ipp.rs:269-276
+    if (G->n < n || H->n < n || G_factors->n < n || H_factors->n < n) return BP_ERR_LENGTH;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    IPP_DISPATCH(ctx->curve, I::verify(ctx, t->t, n, G_factors, H_factors, P_le, Q_le, G, H, a_le32, b_le32, L_le, R_le, lg_n));
+}
+
+// IPP::verification_scalars (ipp.rs:262-315): (u_j^2, u_j^-2, s) as canonical LE scalars; host arithmetic.
+int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, uint8_t* u_sq,
+                                uint8_t* u_inv_sq, uint8_t* s) {
+    if (!curve_ok(curve_id) || !t || !u_sq || !u_inv_sq || !s || (lg_n && (!L_le || !R_le))) return BP_ERR_ARG;
+    auto run = [&](auto tag) -> int {
+        using C = decltype(tag);
+        using F = typename C::Fr;
+        std::vector<Fe<F>> ch, ch_inv;
+        int rc = Ipp<C>::verification_scalars(t->t, L_le, R_le, lg_n, n, ch, ch_inv);
+        if (rc) return rc;
+        std::vector<Fe<F>> usq(lg_n);
+        Fe<F> prod_inv = fe_one<F>();
+        for (size_t j = 0; j < lg_n; j++) {
+            usq[j] = fe_sqr(ch[j]);
+            fr_to_le<F>(usq[j], u_sq + 32 * j);
+            fr_to_le<F>(fe_sqr(ch_inv[j]), u_inv_sq + 32 * j);
+            prod_inv = fe_mul(prod_inv, ch_inv[j]);
+        }
+        std::vector<Fe<F>> sv(n);
+        sv[0] = prod_inv;                                                               // :304
+        for (size_t i = 1; i < n; i++) {                                                // :305-312
+            int lg_i = 63 - __builtin_clzll((unsigned long long)i);
+            sv[i] = fe_mul(sv[i - ((size_t)1 << lg_i)], usq[(lg_n - 1) - lg_i]);
+        }
+        for (size_t i = 0; i < n; i++) fr_to_le<F>(sv[i], s + 32 * i);
+        return BP_OK;
+    };
+    return curve_id == BP_CURVE_BLS12_381 ? run(Bls381{}) : run(Bn254{});
+}
+
+}  // extern "C"

@@ -199,14 +199,17 @@ template <class C> BP_HD Aff<C> generator() {
     return g;
 }
 
-// k * p, k given as NW canonical (non-Montgomery) 32-bit words; plain double-and-add, variable time.
-template <class C> BP_HD_NOINLINE Xyzz<C> xyzz_mul_words(const uint32_t* k, const Aff<C>& p) {
+// k * p, k given as 8 canonical (non-Montgomery) 32-bit words; double-and-add, msb first.  The scalar sits in
+// 64-bit registers shifted left one bit per step (static indexing; leading zeros double the identity).
+template <class C> BP_HD Xyzz<C> xyzz_mul_words(const uint32_t (&k)[8], const Aff<C>& p) {
     Xyzz<C> acc = xyzz_inf<C>();
-    int top = C::Fr::BITS - 1;
-    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
-    for (int i = top; i >= 0; i--) {
+    uint64_t a0 = k[0] | ((uint64_t)k[1] << 32), a1 = k[2] | ((uint64_t)k[3] << 32), a2 = k[4] | ((uint64_t)k[5] << 32),
+             a3 = k[6] | ((uint64_t)k[7] << 32);
+    for (int i = 0; i < 256; i++) {
+        uint32_t bit = (uint32_t)(a3 >> 63);
+        a3 = (a3 << 1) | (a2 >> 63); a2 = (a2 << 1) | (a1 >> 63); a1 = (a1 << 1) | (a0 >> 63); a0 <<= 1;
         acc = xyzz_dbl(acc);
-        if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_add_aff(acc, p);
+        if (bit) acc = xyzz_add_aff(acc, p);
     }
     return acc;
 }

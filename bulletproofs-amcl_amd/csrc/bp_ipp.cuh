@@ -1,0 +1,221 @@
+// bp_ipp.cuh -- gfx950 kernels for the per-round vector work of the inner-product argument.
+//
+// Replaces (device side of) /root/reference src/ipp.rs:
+//   FieldElementVector::inner_product      :77-78, :145-146         -> k_fr_inner / k_fr_inner_final
+//   hadamard_product with G/H factors      :81-82, :94-95           -> fused into k_ipp_pack_round (first round)
+//   L / R term assembly                    :80-104, :148-170        -> k_ipp_pack_round (then the MSM pipeline)
+//   scalar fold + binary_scalar_mul fold   :115-130, :181-188       -> k_ipp_fold  (the reference's dominant CPU cost)
+//   verification scalars / MSM terms       :220-249, :303-312       -> k_ipp_verify_terms
+// Scalars (Fr) live in HBM as canonical 8-word values.  A Montgomery product of a canonical x with a constant held
+// in Montgomery form (u*R) is the canonical product x*u, so folds need no domain conversion.
+#pragma once
+#include "bp_kernels.cuh"
+
+namespace bp {
+
+template <class F>
+__device__ __forceinline__ Fe<F> fr_load(const ScalarWords* v, size_t i) {
+    ScalarWords s = v[i];
+    return fe_unpack_words<F>(s.w);
+}
+template <class F>
+__device__ __forceinline__ void fr_store(ScalarWords* v, size_t i, const Fe<F>& x) {
+    ScalarWords s;
+    fe_pack_words<F>(s.w, x);
+    v[i] = s;
+}
+
+// block-level sum of one Fr value per thread; result valid in thread 0
+template <class F>
+__device__ __forceinline__ Fe<F> block_fr_sum(Fe<F> mine, ScalarWords* lds) {
+    fe_pack_words<F>(lds[threadIdx.x].w, mine);
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            mine = fe_add(mine, fe_unpack_words<F>(lds[threadIdx.x + s].w));
+            fe_pack_words<F>(lds[threadIdx.x].w, mine);
+        }
+        __syncthreads();
+    }
+    return mine;
+}
+
+// partial[blockIdx.x] = sum_i a[i] * b[i] / R over a grid-stride slice (Montgomery-scaled; fixed by the final kernel)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_inner(const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b, size_t n,
+                                                     ScalarWords* __restrict__ partial) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    Fe<F> acc = fe_zero<F>();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc = fe_add(acc, fe_mul(fr_load<F>(a, i), fr_load<F>(b, i)));
+    acc = block_fr_sum<F>(acc, lds);
+    if (threadIdx.x == 0) fr_store<F>(partial, blockIdx.x, acc);
+}
+
+// single block: out[0] = (sum of m partials) * R   (undo the 1/R of the Montgomery products)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_inner_final(const ScalarWords* __restrict__ partial, uint32_t m, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) acc = fe_add(acc, fr_load<F>(partial, i));
+    acc = block_fr_sum<F>(acc, lds);
+    if (threadIdx.x == 0) fr_store<F>(out, 0, fe_to_mont<F>(acc));
+}
+
+// out[i] = a[i] * b[i]   (FieldElementVector::hadamard_product)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_hadamard(const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b, size_t n,
+                                                        ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store<F>(out, i, fe_to_mont<F>(fe_mul(fr_load<F>(a, i), fr_load<F>(b, i))));
+}
+
+// out[i] = a[i] * s   (FieldElementVector::scaled_by); s_mont = s in Montgomery form
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_scale(const ScalarWords* __restrict__ a, ScalarWords s_mont, size_t n, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store<F>(out, i, fe_mul(fr_load<F>(a, i), fe_unpack_words<F>(s_mont.w)));
+}
+
+// out[i] = e^i   (FieldElementVector::new_vandermonde_vector); one lane per element, square-and-multiply on i
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_vandermonde(ScalarWords e_mont, size_t n, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> base = fe_unpack_words<F>(e_mont.w), acc = fe_one<F>();
+    for (size_t k = i; k; k >>= 1) {
+        if (k & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    fr_store<F>(out, i, fe_from_mont<F>(acc));
+}
+
+// ---------------------------------------------------------------------------------------------- IPP round
+// Assemble the MSM terms of L and R for the current round of length n = 2h (src/ipp.rs:80-104 / :148-170):
+//   L: points [G_R | H_L | Q], scalars [a_L (.Gf_R) | b_R (.Hf_L) | c_L]
+//   R: points [G_L | H_R | Q], scalars [a_R (.Gf_L) | b_L (.Hf_R) | c_R]
+// written as two blocks of 2h + 1 terms each (L at 0, R at 2h + 1).  gf/hf == nullptr after the first round.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_ipp_pack_round(const AffPacked<C>* __restrict__ G, const AffPacked<C>* __restrict__ H,
+                                                           const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b,
+                                                           const ScalarWords* __restrict__ gf, const ScalarWords* __restrict__ hf,
+                                                           const AffPacked<C>* __restrict__ Q, const ScalarWords* __restrict__ cLR, size_t h,
+                                                           AffPacked<C>* __restrict__ pts, ScalarWords* __restrict__ sc) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t blk = 2 * h + 1;
+    if (i < h) {
+        pts[i] = G[h + i];            pts[h + i] = H[i];
+        pts[blk + i] = G[i];          pts[blk + h + i] = H[h + i];
+        if (gf) {
+            fr_store<F>(sc, i, fe_to_mont<F>(fe_mul(fr_load<F>(a, i), fr_load<F>(gf, h + i))));
+            fr_store<F>(sc, h + i, fe_to_mont<F>(fe_mul(fr_load<F>(b, h + i), fr_load<F>(hf, i))));
+            fr_store<F>(sc, blk + i, fe_to_mont<F>(fe_mul(fr_load<F>(a, h + i), fr_load<F>(gf, i))));
+            fr_store<F>(sc, blk + h + i, fe_to_mont<F>(fe_mul(fr_load<F>(b, i), fr_load<F>(hf, h + i))));
+        } else {
+            sc[i] = a[i];             sc[h + i] = b[h + i];
+            sc[blk + i] = a[h + i];   sc[blk + h + i] = b[i];
+        }
+    }
+    if (i == 0) {
+        pts[2 * h] = *Q;      sc[2 * h] = cLR[0];
+        pts[blk + 2 * h] = *Q; sc[blk + 2 * h] = cLR[1];
+    }
+}
+
+// k1*p + k2*q with one shared doubling chain (Shamir), k1/k2 canonical words.  (G1::binary_scalar_mul)
+// The two scalars are held in 64-bit registers and shifted left one bit per step (static indexing only: no
+// per-lane scratch arrays, no divergent trip counts -- leading zero bits just double the identity).
+template <class C>
+BP_HD Xyzz<C> xyzz_mul2_words(const ScalarWords& k1, const Aff<C>& p, const ScalarWords& k2, const Aff<C>& q) {
+    Xyzz<C> pq = xyzz_add_aff(xyzz_from_aff(p), q);   // p + q, with p == +-q and identities handled
+    Xyzz<C> acc = xyzz_inf<C>();
+    uint64_t a0 = k1.w[0] | ((uint64_t)k1.w[1] << 32), a1 = k1.w[2] | ((uint64_t)k1.w[3] << 32), a2 = k1.w[4] | ((uint64_t)k1.w[5] << 32),
+             a3 = k1.w[6] | ((uint64_t)k1.w[7] << 32);
+    uint64_t b0 = k2.w[0] | ((uint64_t)k2.w[1] << 32), b1 = k2.w[2] | ((uint64_t)k2.w[3] << 32), b2 = k2.w[4] | ((uint64_t)k2.w[5] << 32),
+             b3 = k2.w[6] | ((uint64_t)k2.w[7] << 32);
+    for (int i = 0; i < 256; i++) {
+        uint32_t ba = (uint32_t)(a3 >> 63), bb = (uint32_t)(b3 >> 63);
+        a3 = (a3 << 1) | (a2 >> 63); a2 = (a2 << 1) | (a1 >> 63); a1 = (a1 << 1) | (a0 >> 63); a0 <<= 1;
+        b3 = (b3 << 1) | (b2 >> 63); b2 = (b2 << 1) | (b1 >> 63); b1 = (b1 << 1) | (b0 >> 63); b0 <<= 1;
+        acc = xyzz_dbl(acc);
+        if (ba & bb) acc = xyzz_add(acc, pq);
+        else if (ba) acc = xyzz_add_aff(acc, p);
+        else if (bb) acc = xyzz_add_aff(acc, q);
+    }
+    return acc;
+}
+
+// One lane per (vector, i):  lanes [0, h) fold G, lanes [h, 2h) fold H; every lane i < h also folds a and b.
+//   a_L[i] = a_L[i] u + u^-1 a_R[i] ;  b_L[i] = b_L[i] u^-1 + u b_R[i]                         (src/ipp.rs:116-117,182-183)
+//   G_L[i] = (u^-1 Gf_L[i]) G_L[i] + (u Gf_R[i]) G_R[i] ;  H_L[i] = (u Hf_L[i]) H_L[i] + (u^-1 Hf_R[i]) H_R[i]   (:119-129,185-187)
+// u_mont / uinv_mont are in Montgomery form.  In place: only the lower halves are written.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_ipp_fold(AffPacked<C>* __restrict__ G, AffPacked<C>* __restrict__ H, ScalarWords* __restrict__ a,
+                                                     ScalarWords* __restrict__ b, const ScalarWords* __restrict__ gf,
+                                                     const ScalarWords* __restrict__ hf, ScalarWords u_mont, ScalarWords uinv_mont, size_t h) {
+    using F = typename C::Fr;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * h) return;
+    Fe<F> u = fe_unpack_words<F>(u_mont.w), ui = fe_unpack_words<F>(uinv_mont.w);
+    bool isH = t >= h;
+    size_t i = isH ? t - h : t;
+    if (!isH) {
+        Fe<F> aL = fr_load<F>(a, i), aR = fr_load<F>(a, h + i), bL = fr_load<F>(b, i), bR = fr_load<F>(b, h + i);
+        fr_store<F>(a, i, fe_add(fe_mul(aL, u), fe_mul(ui, aR)));
+        fr_store<F>(b, i, fe_add(fe_mul(bL, ui), fe_mul(u, bR)));
+    }
+    AffPacked<C>* V = isH ? H : G;
+    const ScalarWords* fac = isH ? hf : gf;
+    // scalar on the left half / right half: G: (u^-1, u), H: (u, u^-1)
+    Fe<F> sL = isH ? u : ui, sR = isH ? ui : u;
+    ScalarWords k1, k2;
+    if (fac) {
+        fe_pack_words<F>(k1.w, fe_mul(fr_load<F>(fac, i), sL));      // canonical * Montgomery constant = canonical product
+        fe_pack_words<F>(k2.w, fe_mul(fr_load<F>(fac, h + i), sR));
+    } else {
+        fe_pack_words<F>(k1.w, fe_from_mont<F>(sL));
+        fe_pack_words<F>(k2.w, fe_from_mont<F>(sR));
+    }
+    Aff<C> p = aff_unpack(V[i]), q = aff_unpack(V[h + i]);
+    Xyzz<C> r = xyzz_mul2_words<C>(k1, p, k2, q);
+    V[i] = aff_pack(xyzz_to_aff<C>(r));
+}
+
+// ---------------------------------------------------------------------------------------------- IPP verification
+// Terms of the single verification MSM (src/ipp.rs:220-249): for i < n
+//   sc[1 + i]     = a * s_i * Gf_i         with  s_i = prod_j u_j^(+1 if bit (lg_n-1-j) of i else -1)     (:303-312)
+//   sc[1 + n + i] = b * s_(n-1-i) * Hf_i   (s_(n-1-i) = 1 / s_i)
+// points [Q | G | H | L | R]; sc[0] = a*b and the -u_j^2 / -u_j^-2 tail are written by the host side.
+// ch[j] / ch_inv[j] (j < lg_n, creation order) and a_mont / b_mont are in Montgomery form.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_ipp_verify_terms(const AffPacked<C>* __restrict__ G, const AffPacked<C>* __restrict__ H,
+                                                             const ScalarWords* __restrict__ gf, const ScalarWords* __restrict__ hf,
+                                                             const ScalarWords* __restrict__ ch, const ScalarWords* __restrict__ ch_inv, int lg_n,
+                                                             ScalarWords a_mont, ScalarWords b_mont, size_t n, AffPacked<C>* __restrict__ pts,
+                                                             ScalarWords* __restrict__ sc) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> s = fe_one<F>(), sinv = fe_one<F>();
+    for (int j = 0; j < lg_n; j++) {
+        bool bit = (i >> (lg_n - 1 - j)) & 1;
+        Fe<F> uj = fr_load<F>(ch, j), ujinv = fr_load<F>(ch_inv, j);
+        s = fe_mul(s, bit ? uj : ujinv);
+        sinv = fe_mul(sinv, bit ? ujinv : uj);
+    }
+    // s, sinv are Montgomery; (a_mont * s) is Montgomery; times canonical factor -> canonical
+    fr_store<F>(sc, 1 + i, fe_mul(fe_mul(fe_unpack_words<F>(a_mont.w), s), fr_load<F>(gf, i)));
+    fr_store<F>(sc, 1 + n + i, fe_mul(fe_mul(fe_unpack_words<F>(b_mont.w), sinv), fr_load<F>(hf, i)));
+    pts[1 + i] = G[i];
+    pts[1 + n + i] = H[i];
+}
+
+}  // namespace bp

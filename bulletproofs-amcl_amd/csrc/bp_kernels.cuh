@@ -67,7 +67,7 @@ __device__ __forceinline__ void add256(uint64_t (&q)[4], const ScalarWords& a, c
 }
 
 // thread per scalar: digit codes (transposed: code[w][i]) + histogram of (window, |digit|)
-__global__ void __launch_bounds__(kBlock) k_digits_count(const ScalarWords* __restrict__ scalars, size_t n, WinTab tab,
+static __global__ void __launch_bounds__(kBlock) k_digits_count(const ScalarWords* __restrict__ scalars, size_t n, WinTab tab,
                                                           uint16_t* __restrict__ code, uint32_t* __restrict__ count) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(kBlock) k_digits_count(const ScalarWords* __re
 
 // grid = (tiles, W): window-major, so that the blocks in flight write one window's slice of idx[] (n words,
 // L2-sized) instead of W slices at once.
-__global__ void __launch_bounds__(kBlock) k_digits_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab,
+static __global__ void __launch_bounds__(kBlock) k_digits_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab,
                                                             uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
     int w = blockIdx.y;
     int c = tab.cw[w];
@@ -127,7 +127,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t
     return base + inc - mine;
 }
 
-__global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ block_sums) {
+static __global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t lds[kBlock / 64];
     size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
     uint32_t s = 0;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_t* __re
 }
 
 // single block: exclusive scan of up to kScanPerBlock * k block sums, in place
-__global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict__ block_sums, size_t nblocks) {
+static __global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict__ block_sums, size_t nblocks) {
     __shared__ uint32_t lds[kBlock / 64];
     uint32_t carry = 0;
     for (size_t chunk = 0; chunk < nblocks; chunk += kScanPerBlock) {
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict__ bloc
 }
 
 // out[i] = exclusive prefix of in; optionally also writes a copy (the scatter cursors).  in/out may alias.
-__global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in, size_t n, const uint32_t* __restrict__ block_sums,
+static __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in, size_t n, const uint32_t* __restrict__ block_sums,
                                                         uint32_t* out, uint32_t* __restrict__ out_copy) {
     __shared__ uint32_t lds[kBlock / 64];
     size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
@@ -184,7 +184,7 @@ constexpr uint32_t kTaskBins = 129;
 __device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = log2(L) - 7
 
 // thread per bucket: ntasks[g], and a histogram of task lengths
-__global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
+static __global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
                                                         uint32_t L, uint32_t lshift, uint32_t* __restrict__ ntasks, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t lh[kTaskBins];
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restric
 }
 
 // single block: bin_count -> exclusive offsets (in place); total task count -> *total
-__global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __restrict__ bin, uint32_t* __restrict__ total) {
+static __global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __restrict__ bin, uint32_t* __restrict__ total) {
     __shared__ uint32_t lds[kBlock / 64];
     static_assert(kTaskBins <= kBlock, "one thread per bin");
     uint32_t v = threadIdx.x < kTaskBins ? bin[threadIdx.x] : 0, tot;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __restrict_
 
 // thread per bucket: emit its tasks.  task id = task_off[g] + k; order[] lists task ids longest first.
 // t_start/t_len describe the slot range of a task.  Buckets with more than one task are appended to heavy[].
-__global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
+static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
                                                        uint32_t L, uint32_t lshift, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ bin_cursor,
                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ t_start, uint32_t* __restrict__ t_len,
                                                        uint32_t* __restrict__ heavy, uint32_t* __restrict__ nheavy) {

@@ -134,6 +134,67 @@ int bp_msm_g1_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_
 int bp_msm_last_timing(bp_ctx* ctx, float* ms, int cap);
 int bp_ctx_enable_timing(bp_ctx* ctx, int on);
 
+/* ---- FieldElementVector kernels --------------------------------------------------------- */
+/* FieldElementVector::inner_product (src/ipp.rs:77,78,145,146; src/utils/vector_poly.rs:44-50,82-87):
+ * out = sum_i a[aoff+i] * b[boff+i] mod r, 32-byte LE.  BP_ERR_LENGTH if a range overruns its vector. */
+int bp_fr_inner_product(bp_ctx* ctx, const bp_frvec* a, size_t aoff, const bp_frvec* b, size_t boff, size_t n, uint8_t* out_le32);
+/* FieldElementVector::hadamard_product (src/ipp.rs:81,82,94,95): BP_ERR_LENGTH on unequal lengths. */
+int bp_fr_hadamard(bp_ctx* ctx, const bp_frvec* a, const bp_frvec* b, bp_frvec** out);
+/* FieldElementVector::scaled_by (src/r1cs/verifier.rs:416). */
+int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_frvec** out);
+/* FieldElementVector::new_vandermonde_vector(e, n) = [1, e, e^2, ...] (src/ipp.rs:348; src/r1cs/prover.rs:463). */
+int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** out);
+/* FieldElement::inverse (src/ipp.rs:113,179); host arithmetic, no GPU needed; inverse of 0 is 0. */
+int bp_fr_inverse(int curve_id, const uint8_t* in_le32, uint8_t* out_le32);
+
+/* ---- transcript: merlin::Transcript + TranscriptProtocol (src/transcript.rs:12-61); host only -------------------- */
+typedef struct bp_transcript bp_transcript;
+int bp_transcript_new(const uint8_t* label, size_t label_len, bp_transcript** out);            /* Transcript::new(label) */
+int bp_transcript_free(bp_transcript* t);
+int bp_transcript_append_message(bp_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
+int bp_transcript_append_u64(bp_transcript* t, const uint8_t* label, size_t label_len, uint64_t x);
+int bp_transcript_challenge_bytes(bp_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
+/* commit_point: append_message(label, G1::to_bytes())          (src/transcript.rs:51-53); point given as BP_FMT_LE */
+int bp_transcript_commit_point(bp_transcript* t, int curve_id, const char* label, const uint8_t* point_le);
+/* commit_scalar: append_message(label, FieldElement::to_bytes()) (src/transcript.rs:47-49) */
+int bp_transcript_commit_scalar(bp_transcript* t, int curve_id, const char* label, const uint8_t* scalar_le32);
+/* challenge_scalar: MODBYTES challenge bytes -> FieldElement::from (src/transcript.rs:55-60) */
+int bp_transcript_challenge_scalar(bp_transcript* t, int curve_id, const char* label, uint8_t* out_le32);
+
+/* ---- inner-product argument ------------------------------------------------------------ */
+/* Device-resident prover state: working copies of G, H, a, b (src/ipp.rs:57-60) stay in HBM for all lg n rounds;
+ * per round only L, R go to the host (for the transcript) and u, u^-1 come back.  For a host that owns its own
+ * transcript (the Rust crate):  state_create; while len > 1 { round -> L,R; [host: commit, challenge]; fold(u, u^-1) };
+ * state_finish -> a, b.
+ * state_create enforces create_ipp's assertions (src/ipp.rs:48-55): n a power of two, all six lengths equal ->
+ * BP_ERR_ARG otherwise. */
+typedef struct bp_ipp_state bp_ipp_state;
+int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* Q_le, const bp_frvec* G_factors,
+                        const bp_frvec* H_factors, const bp_frvec* a, const bp_frvec* b, bp_ipp_state** out);
+size_t bp_ipp_state_len(const bp_ipp_state* st);
+/* L = <a_L(.Gf_R), G_R> + <b_R(.Hf_L), H_L> + c_L Q ;  R = <a_R(.Gf_L), G_L> + <b_L(.Hf_R), H_R> + c_R Q
+ * (src/ipp.rs:77-104 first round, :145-170 later rounds), BP_FMT_LE. */
+int bp_ipp_round(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le);
+/* The fold of src/ipp.rs:115-130 / :181-188 (scalar fold + G1::binary_scalar_mul per element); halves the length. */
+int bp_ipp_fold(bp_ipp_state* st, const uint8_t* u_le32, const uint8_t* u_inv_le32);
+int bp_ipp_state_finish(bp_ipp_state* st, uint8_t* a_le32, uint8_t* b_le32); /* needs len == 1 */
+int bp_ipp_state_free(bp_ipp_state* st);
+
+/* IPP::create_ipp (src/ipp.rs:35-202) with this library's transcript: L_out / R_out receive lg n BP_FMT_LE points
+ * (InnerProductArgumentProof{L, R, a, b}, src/ipp.rs:13-20). */
+int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
+                  const bp_g1vec* H, const bp_frvec* a, const bp_frvec* b, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out,
+                  uint8_t* a_out_le32, uint8_t* b_out_le32);
+/* IPP::verify_ipp (src/ipp.rs:204-260): BP_OK, or BP_ERR_VERIFY (R1CSError::VerificationError) when the single
+ * (1 + 2n + 2 lg n)-term MSM differs from P or when lg_n >= 32 / n != 2^lg_n (src/ipp.rs:269-276). */
+int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_factors, const bp_frvec* H_factors, const uint8_t* P_le,
+                  const uint8_t* Q_le, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* a_le32, const uint8_t* b_le32, const uint8_t* L_le,
+                  const uint8_t* R_le, size_t lg_n);
+/* IPP::verification_scalars (src/ipp.rs:262-315): u_sq / u_inv_sq (lg_n scalars each) and s (n scalars), 32-byte LE.
+ * Host arithmetic (used by the R1CS verifier, src/r1cs/verifier.rs:354); no GPU needed. */
+int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, uint8_t* u_sq,
+                                uint8_t* u_inv_sq, uint8_t* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,189 @@
+"""GPU parity tests for the inner-product argument: FieldElementVector kernels, the round/fold kernels and the whole
+create_ipp / verify_ipp flow through the C ABI, against the golden vectors (Python-int) and the C oracle."""
+import pytest
+
+import __graft_entry__ as G
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bls12_381", "bn254"]
+
+
+def hx(s):
+    return bytes.fromhex(s)
+
+
+@pytest.fixture(scope="module")
+def bp():
+    return G.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctxs(bp):
+    c = {name: bp.Context(cid, 0) for name, cid in bp.CURVE_IDS.items()}
+    yield c
+    for x in c.values():
+        x.close()
+
+
+def ints(b):
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_fr_vector_kernels(bp, ctxs, name):
+    ctx = ctxs[name]
+    r = ctx.r
+    for n in (1, 2, 255, 256, 257, 5000, 70001):
+        ab, bb = O.random_scalars(ctx.curve, 300 + n, n), O.random_scalars(ctx.curve, 400 + n, n)
+        a, b = bp.FieldElementVector.from_bytes(ctx, ab, n), bp.FieldElementVector.from_bytes(ctx, bb, n)
+        assert a.inner_product(b) == O.fr_inner(ctx.curve, ab, bb, n)
+        if n > 4:
+            assert a.inner_product(b, aoff=1, boff=3, n=n - 3) == O.fr_inner(ctx.curve, ab[32:], bb[96:], n - 3)
+        ai, bi = ints(ab), ints(bb)
+        if n <= 5000:
+            assert ints(a.hadamard_product(b).to_bytes()) == [x * y % r for x, y in zip(ai, bi)]
+            s = bi[0]
+            assert ints(a.scaled_by(bb[:32]).to_bytes()) == [x * s % r for x in ai]
+            assert ints(bp.FieldElementVector.new_vandermonde_vector(ctx, bb[:32], n).to_bytes()) == [pow(s, i, r) for i in range(n)]
+    a3 = bp.FieldElementVector.from_ints(ctx, [1, 2, 3])
+    a4 = bp.FieldElementVector.from_ints(ctx, [1, 2, 3, 4])
+    with pytest.raises(bp.ValueError_):
+        a3.inner_product(a4)
+    with pytest.raises(bp.ValueError_):
+        a3.hadamard_product(a4)
+    assert bp.FieldElementVector.from_ints(ctx, [0, 1, r - 1]).inner_product(bp.FieldElementVector.from_ints(ctx, [5, r - 1, r - 1])) == \
+        ((r - 1 + (r - 1) * (r - 1)) % r).to_bytes(32, "little")
+
+
+def load_case(bp, ctx, c):
+    n = c["n"]
+    cat = lambda k: b"".join(hx(x) for x in c[k])
+    Gv = bp.G1Vector.from_bytes(ctx, cat("G"), n)
+    Hv = bp.G1Vector.from_bytes(ctx, cat("H"), n)
+    Gf = bp.FieldElementVector.from_bytes(ctx, cat("G_factors"), n)
+    Hf = bp.FieldElementVector.from_bytes(ctx, cat("H_factors"), n)
+    a = bp.FieldElementVector.from_bytes(ctx, cat("a"), n)
+    b = bp.FieldElementVector.from_bytes(ctx, cat("b"), n)
+    return n, Gv, Hv, Gf, Hf, a, b
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ipp_golden_create_and_verify(bp, ctxs, golden, name):
+    """Includes the reference's own two unit tests (src/ipp.rs:325-390 n=4, :393-489 n=8 padded) as fixtures."""
+    ctx = ctxs[name]
+    for c in golden("ipp")[name]:
+        n, Gv, Hv, Gf, Hf, a, b = load_case(bp, ctx, c)
+        Q, P = hx(c["Q"]), hx(c["P"])
+        tr = bp.Transcript(b"innerproduct")
+        proof = bp.IPP.create_ipp(ctx, tr, Q, Gf, Hf, Gv, Hv, a, b)
+        assert proof.L == b"".join(hx(x) for x in c["L"]), c["name"]
+        assert proof.R == b"".join(hx(x) for x in c["R"]), c["name"]
+        assert proof.a == hx(c["a_out"]) and proof.b == hx(c["b_out"])
+        assert tr.challenge_bytes(b"after", 32).hex() == c["transcript_after"]
+        # inputs are borrowed and cloned (src/ipp.rs:57-60): the caller's vectors are untouched
+        assert Gv.to_bytes() == b"".join(hx(x) for x in c["G"]) and a.to_bytes() == b"".join(hx(x) for x in c["a"])
+        bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+        bad_a = ((int.from_bytes(proof.a, "little") + 1) % ctx.r).to_bytes(32, "little")
+        with pytest.raises(bp.VerificationError):
+            bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, bad_a, proof.b, proof.L, proof.R)
+        if proof.L:
+            badL = proof.R[:ctx.point_bytes] + proof.L[ctx.point_bytes:]
+            with pytest.raises(bp.VerificationError):
+                bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, badL, proof.R)
+        with pytest.raises(bp.VerificationError):       # wrong n (src/ipp.rs:274-276)
+            bp.IPP.verify_ipp(ctx, 2 * n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ipp_argument_checks(bp, ctxs, name):
+    """create_ipp's assert!/assert_eq! (src/ipp.rs:48-55) surface as ArgError."""
+    ctx = ctxs[name]
+    g = O.generator(ctx.curve)
+    G3, G4 = bp.G1Vector.from_bytes(ctx, g * 3, 3), bp.G1Vector.from_bytes(ctx, g * 4, 4)
+    f3, f4 = bp.FieldElementVector.from_ints(ctx, [1, 2, 3]), bp.FieldElementVector.from_ints(ctx, [1, 2, 3, 4])
+    with pytest.raises(bp.ArgError):
+        bp.IPP.create_ipp(ctx, bp.Transcript(b"x"), g, f3, f3, G3, G3, f3, f3)       # not a power of two
+    with pytest.raises(bp.ArgError):
+        bp.IPP.create_ipp(ctx, bp.Transcript(b"x"), g, f4, f4, G4, G4, f4, f3)       # unequal lengths
+
+
+def make_instance(bp, ctx, n, seed, unit_gf=True):
+    cid = ctx.curve
+    gk, hk = O.random_scalars(cid, seed, n), O.random_scalars(cid, seed + 1, n)
+    Gv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, gk, n))
+    Hv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, hk, n))
+    Q = O.g1_mul(cid, O.random_scalars(cid, seed + 2, 1), O.generator(cid))
+    ab, bb = O.random_scalars(cid, seed + 3, n), O.random_scalars(cid, seed + 4, n)
+    y_inv = O.random_scalars(cid, seed + 5, 1)
+    Hf = bp.FieldElementVector.new_vandermonde_vector(ctx, y_inv, n)                 # as in the reference's tests
+    Gf = bp.FieldElementVector.from_ints(ctx, [1] * n) if unit_gf else bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, seed + 6, n), n)
+    a, b = bp.FieldElementVector.from_bytes(ctx, ab, n), bp.FieldElementVector.from_bytes(ctx, bb, n)
+    return Gv, Hv, Q, Gf, Hf, a, b
+
+
+def commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b):
+    """P = <a.Gf, G> + <b.Hf, H> + <a,b> Q  (the reference's test construction, src/ipp.rs:353-372)."""
+    n = len(Gv)
+    pts = bp.G1Vector.from_bytes(ctx, Gv.to_bytes() + Hv.to_bytes() + Q, 2 * n + 1)
+    sc = bp.FieldElementVector.from_bytes(ctx, a.hadamard_product(Gf).to_bytes() + b.hadamard_product(Hf).to_bytes() + a.inner_product(b), 2 * n + 1)
+    return pts.multi_scalar_mul_var_time(sc)
+
+
+@pytest.mark.parametrize("name,n,unit_gf", [("bls12_381", 64, True), ("bls12_381", 32, False), ("bn254", 64, True), ("bn254", 256, False)])
+def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf):
+    """BASELINE config 1 shape (n = 64): GPU proof bit-for-bit equal to the oracle's, accepted by both verifiers."""
+    ctx = ctxs[name]
+    cid = ctx.curve
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 7000 + n, unit_gf)
+    proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(),
+                            b.to_bytes(), n)
+    assert rc == 0
+    assert (proof.L, proof.R, proof.a, proof.b) == want
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+    assert O.ipp_verify(cid, O.Transcript(b"innerproduct"), n, Gf.to_bytes(), Hf.to_bytes(), P, Q, Gv.to_bytes(), Hv.to_bytes(), proof.a, proof.b,
+                        proof.L, proof.R, proof.lg_n) == 0
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ipp_round_api_with_external_transcript(bp, ctxs, name):
+    """The low-level state API driven by a transcript the caller owns (here: the oracle's), as a Rust host would."""
+    ctx = ctxs[name]
+    cid = ctx.curve
+    n = 16
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 9100)
+    st = bp.IPPState(ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    tr = O.Transcript(b"innerproduct")
+    tr.append_message(b"dom-sep", b"ipp v1")
+    tr.append_message(b"n", n.to_bytes(8, "little"))
+    Ls, Rs = b"", b""
+    while len(st) > 1:
+        L, R = st.round()
+        tr.commit_point(cid, b"L", L)
+        tr.commit_point(cid, b"R", R)
+        u = tr.challenge_scalar(cid, b"u")
+        st.fold(u, bp.fr_inverse(cid, u))
+        Ls, Rs = Ls + L, Rs + R
+    a0, b0 = st.finish()
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(),
+                            b.to_bytes(), n)
+    assert (Ls, Rs, a0, b0) == want
+
+
+def test_ipp_bn254_n4096_config5(bp, ctxs):
+    """BASELINE config 5: BN254 IPP at n = 2^12 -- create on the GPU, verify on the GPU, cross-verify with the oracle."""
+    ctx = ctxs["bn254"]
+    cid = ctx.curve
+    n = 4096
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 12000)
+    proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert proof.lg_n == 12
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+    assert O.ipp_verify(cid, O.Transcript(b"innerproduct"), n, Gf.to_bytes(), Hf.to_bytes(), P, Q, Gv.to_bytes(), Hv.to_bytes(), proof.a, proof.b,
+                        proof.L, proof.R, 12) == 0
+    bad = bytearray(proof.b); bad[0] ^= 1
+    with pytest.raises(bp.VerificationError):
+        bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, bytes(bad), proof.L, proof.R)
