@@ -33,12 +33,16 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
     t.W = W;
     uint32_t bias[8] = {0};
     int off = 0;
-    uint32_t nb = 0, maxB = 0;
+    uint32_t nb = 0, maxB = 0, rows = 0;
     for (int w = 0; w < W; w++) {
         int cw = base + (w < extra ? 1 : 0);
         t.cw[w] = (uint8_t)cw;
         t.off[w] = (uint16_t)off;
         t.boff[w] = nb;
+        int fb = cw - 1 < 8 ? cw - 1 : 8;
+        t.fbits[w] = (uint8_t)fb;
+        t.hoff[w] = (uint16_t)rows;
+        rows += 1u << (cw - 1 - fb);
         uint32_t B = 1u << (cw - 1);
         nb += B;
         if (B > maxB) maxB = B;
@@ -57,10 +61,13 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
         off += cw;
     }
     t.boff[W] = nb;
+    t.hoff[W] = (uint16_t)rows;
     t.nbuckets = nb;
     memcpy(t.bias.w, bias, sizeof bias);
+    static const uint32_t m_env = getenv("BP_REDUCE_M") ? (uint32_t)atoi(getenv("BP_REDUCE_M")) : 0;
     uint32_t m = 1;
     while (m < 8 && nb / m > 65536) m <<= 1;
+    if (m_env) m = m_env;
     g.m = m;
     uint32_t T = (maxB + m - 1) / m;
     g.bpw = (T + kBlock - 1) / kBlock;
@@ -102,7 +109,6 @@ struct Impl {
         if ((rc = ctx->cursor.reserve(nb * 4))) return rc;
         if ((rc = ctx->ntasks.reserve(nb * 4))) return rc;
         if ((rc = ctx->task_off.reserve(nb * 4))) return rc;
-        if ((rc = ctx->block_sums.reserve(scan_blocks * 4 + 16))) return rc;
         if ((rc = ctx->idx.reserve((size_t)W * n * 4))) return rc;
         if ((rc = ctx->code.reserve((size_t)W * n * 2))) return rc;
         if ((rc = ctx->order.reserve(max_tasks * 4))) return rc;
@@ -117,7 +123,7 @@ struct Impl {
         uint32_t* cursor = (uint32_t*)ctx->cursor.p;     // scatter cursors, then bucket ends
         uint32_t* ntasks = (uint32_t*)ctx->ntasks.p;
         uint32_t* task_off = (uint32_t*)ctx->task_off.p;
-        uint32_t* bsum = (uint32_t*)ctx->block_sums.p;
+        uint32_t* bsum = nullptr;
         uint32_t* idx = (uint32_t*)ctx->idx.p;
         uint16_t* code = (uint16_t*)ctx->code.p;
         uint32_t* order = (uint32_t*)ctx->order.p;
@@ -133,24 +139,31 @@ struct Impl {
 
         bool tm = ctx->timing;
         if (tm) { if ((rc = ensure_events(ctx))) return rc; HIPCHK(hipEventRecord(ctx->ev[0], st)); }
-        HIPCHK(hipMemsetAsync(count, 0, nb * 4, st));
         HIPCHK(hipMemsetAsync(bins, 0, (kTaskBins + 2) * 4, st));
-        unsigned sgrid = (unsigned)((n + kBlock - 1) / kBlock);
-        if (sgrid > 256 * 16) sgrid = 256 * 16;
-        hipLaunchKernelGGL(k_digits_count, dim3(sgrid), dim3(kBlock), 0, st, sc, n, tab, code, count);
-        BP_TRACE_SYNC(ctx, "k_digits_count");
+        const uint32_t ntiles = (uint32_t)((n + kTile - 1) / kTile);
+        const uint32_t rows = tab.hoff[W];
+        const size_t nhist = (size_t)rows * ntiles;
+        const size_t hist_blocks = (nhist + kScanPerBlock - 1) / kScanPerBlock;
+        if ((rc = ctx->tile_hist.reserve(nhist * 4))) return rc;
+        if ((rc = ctx->tmp_code.reserve((size_t)W * n * 2))) return rc;
+        if ((rc = ctx->tmp_idx.reserve((size_t)W * n * 4))) return rc;
+        if ((rc = ctx->block_sums.reserve((hist_blocks > scan_blocks ? hist_blocks : scan_blocks) * 4 + 16))) return rc;
+        bsum = (uint32_t*)ctx->block_sums.p;
+        uint32_t* tile_hist = (uint32_t*)ctx->tile_hist.p;
+        uint16_t* tmp_code = (uint16_t*)ctx->tmp_code.p;
+        uint32_t* tmp_idx = (uint32_t*)ctx->tmp_idx.p;
+        hipLaunchKernelGGL(k_digits_bin, dim3(ntiles), dim3(kBlock), 0, st, sc, n, tab, ntiles, code, tile_hist);
+        BP_TRACE_SYNC(ctx, "k_digits_bin");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
-        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, count, nb, bsum);
-        BP_TRACE_SYNC(ctx, "k_scan_block_sums");
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, bsum, scan_blocks);
-        BP_TRACE_SYNC(ctx, "k_scan_top");
-        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, count, nb, bsum, count, cursor);
-        BP_TRACE_SYNC(ctx, "k_scan_apply");
+        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, bsum, hist_blocks);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, bsum, tile_hist, (uint32_t*)nullptr);
+        BP_TRACE_SYNC(ctx, "scan tile_hist");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
-        unsigned tgrid = (unsigned)((n + kBlock - 1) / kBlock);
-        if (tgrid > 1024) tgrid = 1024;
-        hipLaunchKernelGGL(k_digits_scatter, dim3(tgrid, W), dim3(kBlock), 0, st, code, n, tab, cursor, idx);
-        BP_TRACE_SYNC(ctx, "k_digits_scatter");
+        hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, W), dim3(kBlock), 0, st, code, n, tab, ntiles, tile_hist, tmp_code, tmp_idx);
+        BP_TRACE_SYNC(ctx, "k_coarse_scatter");
+        hipLaunchKernelGGL(k_fine_place, dim3(128, W), dim3(kBlock), 0, st, tmp_code, tmp_idx, tab, ntiles, tile_hist, bsum + hist_blocks, count, cursor, idx);
+        BP_TRACE_SYNC(ctx, "k_fine_place");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[3], st));
         // count[] = bucket starts, cursor[] = bucket ends.  Tasks:
         unsigned bgrid = (unsigned)((nb + kBlock - 1) / kBlock);
@@ -167,9 +180,13 @@ struct Impl {
         hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len, heavy, nheavy);
         BP_TRACE_SYNC(ctx, "k_task_emit");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));
-        hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((max_tasks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pts, idx, order, t_start, t_len,
-                           total_tasks, tsum);
-        BP_TRACE_SYNC(ctx, "k_accumulate<C>");
+        {
+            dim3 agrid((unsigned)((max_tasks + kBlock - 1) / kBlock));
+            static const int wps = getenv("BP_ACC_WPS") ? atoi(getenv("BP_ACC_WPS")) : 3;
+            if (wps == 2) hipLaunchKernelGGL((k_accumulate<C, 2>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
+            else if (wps == 4) hipLaunchKernelGGL((k_accumulate<C, 4>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
+            else hipLaunchKernelGGL((k_accumulate<C, 3>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
+        }
         if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
         hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)max_heavy), dim3(64), 0, st, heavy, nheavy, task_off, ntasks, tsum);
         BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
@@ -348,7 +365,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     if (!ctx) return BP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
+    for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_code, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
                       &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch}) b->release();
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->ev_ready) for (auto& e : ctx->ev) (void)hipEventDestroy(e);

@@ -40,7 +40,7 @@ struct bp_ctx {
     int c_override = 0;
     bool timing = false;
     // MSM workspace
-    DevBuf count, cursor, block_sums, idx, code, ntasks, task_off, order, t_start, t_len, tsum, heavy, meta, partial, window_sum, scratch;
+    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_code, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, meta, partial, window_sum, scratch;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     hipEvent_t ev[8] = {};

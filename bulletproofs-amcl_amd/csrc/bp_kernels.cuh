@@ -8,12 +8,12 @@
 //
 // Pipeline for  sum_i s_i P_i  with W signed windows of (nearly) equal width c covering bits+1 bits, window w
 // owning 2^(c_w - 1) buckets (bucket j <-> |digit| = j + 1):
-//   k_digits_count   thread per scalar: k' = k + bias, 16-bit digit code per window (stored transposed,
-//                    code[w][i]) and histogram of (window, |digit|) -> count[]
-//   k_scan_*         exclusive scan of count[] -> bucket start offsets (+ copy = scatter cursors)
-//   k_digits_scatter grid (tiles, W), window-major: claim a slot per (window, |digit|), write point index (+ sign
-//                    bit) -> idx[]   (order inside a bucket is arbitrary: the sum is commutative and the result is
-//                    compared in canonical affine form)
+//   k_digits_bin     block per tile: k' = k + bias, 16-bit digit code per window (stored transposed, code[w][i]) and
+//                    LDS histograms over coarse bins of the bucket id
+//   k_scan_*         exclusive scan of the (bin, tile) histogram
+//   k_coarse_scatter / k_fine_place   two-level placement of point indices (+ sign bit) into idx[], grouped by
+//                    (window, bucket), and bucket start/end offsets (order inside a bucket is arbitrary: the sum is
+//                    commutative and the result is compared in canonical affine form)
 //   k_task_*         cut buckets into tasks of <= kTaskLen points, order tasks longest first
 //   k_accumulate     lane per task: XYZZ accumulator in VGPRs, gathers its points (96-B rows, 16-B vector loads) and
 //                    mixed-adds them
@@ -48,8 +48,13 @@ struct WinTab {
     uint8_t cw[kMaxWindows];
     uint16_t off[kMaxWindows];
     uint32_t boff[kMaxWindows + 1];
+    uint8_t fbits[kMaxWindows];        // fine bits of a bucket id: min(8, cw - 1); the rest are the coarse bin
+    uint16_t hoff[kMaxWindows + 1];    // first coarse-bin row of window w in the tile histogram (hoff[W] = rows)
     ScalarWords bias;   // H = sum_w (2^(cw-1) - 1) 2^off[w]
 };
+
+constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane)
+constexpr int kMaxBinRows = 2048;      // sum over windows of coarse bins (c = 16: 16 x 128)
 
 // Signed-digit recoding without a serial carry: with k' = k + H, the raw cw-bit window w of k' equals
 // digit_w + (2^(cw-1) - 1), digit_w in [-(2^(cw-1) - 1), 2^(cw-1)], sum_w digit_w 2^off[w] = k.  (Adding
@@ -66,41 +71,109 @@ __device__ __forceinline__ void add256(uint64_t (&q)[4], const ScalarWords& a, c
     }
 }
 
-// thread per scalar: digit codes (transposed: code[w][i]) + histogram of (window, |digit|)
-static __global__ void __launch_bounds__(kBlock) k_digits_count(const ScalarWords* __restrict__ scalars, size_t n, WinTab tab,
-                                                          uint16_t* __restrict__ code, uint32_t* __restrict__ count) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint64_t q[4];
-        add256(q, scalars[i], tab.bias);
-        for (int w = 0; w < tab.W; w++) {
-            int c = tab.cw[w];
-            uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);
-            q[0] = (q[0] >> c) | (q[1] << (64 - c));
-            q[1] = (q[1] >> c) | (q[2] << (64 - c));
-            q[2] = (q[2] >> c) | (q[3] << (64 - c));
-            q[3] >>= c;
-            code[(size_t)w * n + i] = (uint16_t)raw;
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* lds, uint32_t& block_total);
+
+// Sorting point indices by (window, bucket) -- a two-level binning sort, all atomics in LDS:
+//   k_digits_bin   block per tile of kTile scalars: digit codes (transposed store code[w][i]) and, per window, an LDS
+//                  histogram over COARSE bins (the top bits of the bucket id) -> tile_hist[(row(w,bin)) * ntiles + tile]
+//   scan           exclusive scan of tile_hist: element offsets, window-major / bin-major / tile-minor
+//   k_coarse_scatter  grid (tiles, W): every (tile, bin) run is written contiguously (>= 64-byte runs on average)
+//   k_fine_place   grid (coarse bins, W): one block owns a coarse bin (~8192 elements, 256 buckets): LDS histogram of
+//                  the fine bits -> bucket start/end, then placement into idx[]; the bin's output region is ~32 KB, so
+//                  the 4-byte stores combine in L2 instead of costing a 64-byte write-back each.
+// (The first version -- global-atomic histogram + global random scatter -- took 0.63 + 1.48 ms at n = 2^20 with 1.0 GB
+// of WRITE_SIZE for 64 MB of useful output: profiles/r01_bench_n1_pmc_hbm.json.)
+static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords* __restrict__ scalars, size_t n, WinTab tab, uint32_t ntiles,
+                                                             uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
+    __shared__ uint32_t lh[kMaxBinRows];
+    const uint32_t rows = tab.hoff[tab.W];
+    for (uint32_t k = threadIdx.x; k < rows; k += kBlock) lh[k] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * kTile;
+#pragma unroll 1
+    for (int e = 0; e < kTile / kBlock; e++) {
+        size_t i = base + (size_t)e * kBlock + threadIdx.x;
+        if (i < n) {
+            uint64_t q[4];
+            add256(q, scalars[i], tab.bias);
+            for (int w = 0; w < tab.W; w++) {
+                int c = tab.cw[w];
+                uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);
+                q[0] = (q[0] >> c) | (q[1] << (64 - c));
+                q[1] = (q[1] >> c) | (q[2] << (64 - c));
+                q[2] = (q[2] >> c) | (q[3] << (64 - c));
+                q[3] >>= c;
+                code[(size_t)w * n + i] = (uint16_t)raw;
+                int d = (int)raw - ((1 << (c - 1)) - 1);
+                if (d != 0) atomicAdd(&lh[tab.hoff[w] + (((uint32_t)(d < 0 ? -d : d) - 1) >> tab.fbits[w])], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < rows; k += kBlock) tile_hist[(size_t)k * ntiles + blockIdx.x] = lh[k];
+}
+
+// grid = (ntiles, W).  tile_off = scanned tile_hist.  Writes (code, point index) pairs grouped by coarse bin.
+static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab, uint32_t ntiles,
+                                                                 const uint32_t* __restrict__ tile_off, uint16_t* __restrict__ tmp_code,
+                                                                 uint32_t* __restrict__ tmp_idx) {
+    __shared__ uint32_t lcur[128];
+    const int w = blockIdx.y;
+    const int c = tab.cw[w], fb = tab.fbits[w];
+    const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
+    for (uint32_t k = threadIdx.x; k < nbins; k += kBlock) lcur[k] = tile_off[(size_t)(tab.hoff[w] + k) * ntiles + blockIdx.x];
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * kTile;
+#pragma unroll
+    for (int e = 0; e < kTile / kBlock; e++) {
+        size_t i = base + (size_t)e * kBlock + threadIdx.x;
+        if (i < n) {
+            uint32_t raw = code[(size_t)w * n + i];
             int d = (int)raw - ((1 << (c - 1)) - 1);
-            if (d != 0) atomicAdd(&count[tab.boff[w] + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+            if (d != 0) {
+                uint32_t pos = atomicAdd(&lcur[((uint32_t)(d < 0 ? -d : d) - 1) >> fb], 1u);
+                tmp_code[pos] = (uint16_t)raw;
+                tmp_idx[pos] = (uint32_t)i;
+            }
         }
     }
 }
 
-// grid = (tiles, W): window-major, so that the blocks in flight write one window's slice of idx[] (n words,
-// L2-sized) instead of W slices at once.
-static __global__ void __launch_bounds__(kBlock) k_digits_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab,
-                                                            uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
-    int w = blockIdx.y;
-    int c = tab.cw[w];
-    uint32_t base = tab.boff[w];
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        int d = (int)code[(size_t)w * n + i] - ((1 << (c - 1)) - 1);
-        if (d != 0) {
-            uint32_t slot = atomicAdd(&cursor[base + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
-            idx[slot] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-        }
+// grid = (128, W); block (bin, w) owns the elements [tile_off[row * ntiles], tile_off[(row + 1) * ntiles]) of its
+// coarse bin (row = hoff[w] + bin; `total` closes the last row).  Two streaming passes over them: fine histogram,
+// then placement.  Writes start[g] / end[g] for its 2^fbits buckets and idx[] (point index + sign bit).
+static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint16_t* __restrict__ tmp_code, const uint32_t* __restrict__ tmp_idx, WinTab tab,
+                                                             uint32_t ntiles, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ total,
+                                                             uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx) {
+    __shared__ uint32_t lh[kBlock], lscan[kBlock / 64];
+    const int w = blockIdx.y;
+    const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
+    if (blockIdx.x >= nbins) return;
+    const int c = tab.cw[w], fb = tab.fbits[w];
+    const uint32_t row = tab.hoff[w] + blockIdx.x, rows = tab.hoff[tab.W];
+    const uint32_t lo = tile_off[(size_t)row * ntiles];
+    const uint32_t hi = row + 1 < rows ? tile_off[(size_t)(row + 1) * ntiles] : *total;
+    const uint32_t fmask = (1u << fb) - 1, half1 = (1u << (c - 1)) - 1;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+        int d = (int)tmp_code[j] - (int)half1;
+        atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+    }
+    __syncthreads();
+    uint32_t cnt = lh[threadIdx.x], tot;
+    uint32_t ex = block_exclusive_scan(cnt, lscan, tot) + lo;
+    if (threadIdx.x <= fmask) {
+        uint32_t g = tab.boff[w] + (blockIdx.x << fb) + threadIdx.x;
+        start[g] = ex;
+        end[g] = ex + cnt;
+    }
+    lh[threadIdx.x] = ex;
+    __syncthreads();
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+        int d = (int)tmp_code[j] - (int)half1;
+        uint32_t pos = atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+        idx[pos] = tmp_idx[j] | (d < 0 ? 0x80000000u : 0u);
     }
 }
 
@@ -138,7 +211,7 @@ static __global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// single block: exclusive scan of up to kScanPerBlock * k block sums, in place
+// single block: exclusive scan of the block sums, in place; block_sums[nblocks] receives the grand total
 static __global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict__ block_sums, size_t nblocks) {
     __shared__ uint32_t lds[kBlock / 64];
     uint32_t carry = 0;
@@ -153,6 +226,7 @@ static __global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict
         for (int j = 0; j < kScanPerThread; j++) { if (base + j < nblocks) block_sums[base + j] = ex; ex += v[j]; }
         carry += tot;
     }
+    if (threadIdx.x == 0) block_sums[nblocks] = carry;   // grand total, one slot past the block sums
 }
 
 // out[i] = exclusive prefix of in; optionally also writes a copy (the scatter cursors).  in/out may alias.
@@ -257,9 +331,10 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
 
 // ---------------------------------------------------------------------------------------------- bucket accumulate
 // One lane per task.  The accumulator (4 x 13 limbs) lives in VGPRs for the whole run; points are gathered as
-// 96-byte rows with 16-byte vector loads.  tsum[task] receives the task's sum.
-template <class C>
-__global__ void __launch_bounds__(kBlock) k_accumulate(const AffPacked<C>* __restrict__ pts, const uint32_t* __restrict__ idx,
+// 96-byte rows with 16-byte vector loads.  tsum[task] receives the task's sum.  WPS = waves per SIMD the register
+// allocator is asked to fit (2: 174 VGPRs, 3: 168 VGPRs + 16 B scratch, 4: 128 VGPRs + spills, for BLS12-381).
+template <class C, int WPS>
+__global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* __restrict__ pts, const uint32_t* __restrict__ idx,
                                                        const uint32_t* __restrict__ order, const uint32_t* __restrict__ t_start,
                                                        const uint32_t* __restrict__ t_len, const uint32_t* __restrict__ total_tasks,
                                                        XyzzPacked<C>* __restrict__ tsum) {
