@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "bp_internal.hpp"
+#include "bp_host_tail.hpp"
 
 using namespace bp;
 
@@ -20,7 +21,7 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
     if (c <= 0) {
         int lg = 0;
         while (((size_t)1 << (lg + 1)) <= n) lg++;
-        c = lg - 4;
+        c = lg - 1;   // measured (scripts/time_msm.py sweeps): short per-bucket chains beat fewer buckets up to c = 16
     }
     if (c < 2) c = 2;
     if (c > 16) c = 16;
@@ -210,7 +211,10 @@ struct Impl {
         ctx->last_ms_n = 7;
     }
 
-    // Host stage: fold `sets` sets of W window sums (host memory, packed XYZZ) into one affine point.
+    static const host::Tail<C>& tail() { static const host::Tail<C> t; return t; }
+
+    // Host stage (reference form, 30-bit-limb templates; the production path is host::Tail, bp_host_tail.hpp):
+    // fold `sets` sets of W window sums (host memory, packed XYZZ) into one affine point.
     //   result = sum_w 2^(off_w) * (sum_s rec[s][w])     (Horner over the windows, cw[w] doublings per step)
     static void fold_windows(const XyzzPacked<C>* rec, size_t sets, const MsmGeom& g, Aff<C>& out) {
         const int W = g.tab.W;
@@ -239,9 +243,7 @@ struct Impl {
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        Aff<C> r;
-        fold_windows((const XyzzPacked<C>*)ctx->host_pinned, 1, g, r);
-        aff_to_le(r, out_le);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, g.tab.W, g.tab.cw, out_le);
         return BP_OK;
     }
 
@@ -262,9 +264,7 @@ struct Impl {
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, device_records, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        Aff<C> r;
-        fold_windows((const XyzzPacked<C>*)ctx->host_pinned, sets, g, r);
-        aff_to_le(r, out_le);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, sets, g.tab.W, g.tab.cw, out_le);
         return BP_OK;
     }
 
