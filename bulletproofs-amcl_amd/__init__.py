@@ -108,6 +108,7 @@ SYMBOLS = {
     "bp_transcript_challenge_scalar": (_I, [_P, _I, _U8P, _U8P]),
     "bp_ipp_state_create": (_I, [_P, _P, _P, _U8P, _P, _P, _P, _P, _PP]),
     "bp_ipp_state_len": (_SZ, [_P]),
+    "bp_ctx_set_ipp_fold_generators": (_I, [_P, _I]),
     "bp_ipp_round": (_I, [_P, _U8P, _U8P]),
     "bp_ipp_fold": (_I, [_P, _U8P, _U8P]),
     "bp_ipp_state_finish": (_I, [_P, _U8P, _U8P]),
@@ -193,6 +194,9 @@ class Context:
 
     def set_window_bits(self, c):
         _check(lib().bp_ctx_set_window_bits(self.h, c), "bp_ctx_set_window_bits")
+
+    def set_ipp_fold_generators(self, on):
+        _check(lib().bp_ctx_set_ipp_fold_generators(self.h, 1 if on else 0), "bp_ctx_set_ipp_fold_generators")
 
     def enable_timing(self, on=True):
         _check(lib().bp_ctx_enable_timing(self.h, 1 if on else 0), "bp_ctx_enable_timing")

@@ -25,6 +25,9 @@ struct bp_ipp_state {
     void *pts_tmp, *sc_tmp;  // MSM terms of L and R
     void *cLR;               // c_L, c_R
     void *partial;           // inner-product block partials
+    // default mode (generators never folded, see bp_ipp.cuh): resident [G | H | Q], coefficient vectors, L/R scalars
+    bool fold_generators;
+    void *Pall, *cG, *cH, *sL, *sR;
 };
 
 namespace {
@@ -98,6 +101,16 @@ struct Ipp {
         int rc;
         if ((rc = inner(ctx, a, b + h, h, (ScalarWords*)st->partial, cLR))) return rc;          // c_L = <a_L, b_R>
         if ((rc = inner(ctx, a + h, b, h, (ScalarWords*)st->partial, cLR + 1))) return rc;      // c_R = <a_R, b_L>
+        if (!st->fold_generators) {
+            size_t m = 2 * st->n0 + 1;
+            hipLaunchKernelGGL(k_ipp_round_scalars<C>, dim3(blocks_for(st->n0)), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG,
+                               (const ScalarWords*)st->cH, cLR, st->n0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
+            HIPCHK(hipGetLastError());
+            BP_TRACE_SYNC(ctx, "ipp round scalars");
+            if ((rc = bp_internal_msm(ctx, st->Pall, st->sL, m, L_le))) return rc;
+            if ((rc = bp_internal_msm(ctx, st->Pall, st->sR, m, R_le))) return rc;
+            return BP_OK;
+        }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
                            (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,
                            st->first ? (const ScalarWords*)st->hf : nullptr, (const AffPacked<C>*)st->Q, cLR, h, (AffPacked<C>*)st->pts_tmp,
@@ -114,6 +127,15 @@ struct Ipp {
         bp_ctx* ctx = st->ctx;
         size_t h = st->n / 2;
         Fe<F> u = fr_from_le<F>(u_le), ui = fr_from_le<F>(uinv_le);
+        if (!st->fold_generators) {
+            hipLaunchKernelGGL(k_ipp_fold_scalars<C>, dim3(blocks_for(st->n0)), dim3(kBlock), 0, ctx->stream, (ScalarWords*)st->a, (ScalarWords*)st->b,
+                               (ScalarWords*)st->cG, (ScalarWords*)st->cH, fr_mont_words<F>(u), fr_mont_words<F>(ui), st->n0, st->n);
+            HIPCHK(hipGetLastError());
+            BP_TRACE_SYNC(ctx, "ipp fold scalars");
+            st->n = h;
+            st->first = false;
+            return BP_OK;
+        }
         BP_TRACE_SYNC(ctx, "ipp fold: launching");
         hipLaunchKernelGGL(k_ipp_fold<C>, dim3(blocks_for(2 * h)), dim3(kBlock), 0, ctx->stream, (AffPacked<C>*)st->G, (AffPacked<C>*)st->H,
                            (ScalarWords*)st->a, (ScalarWords*)st->b, st->first ? (const ScalarWords*)st->gf : nullptr,
@@ -356,7 +378,8 @@ int bp_ipp_state_free(bp_ipp_state* st) {
     if (!st) return BP_OK;
     (void)hipSetDevice(st->ctx->device);
     (void)hipStreamSynchronize(st->ctx->stream);
-    for (void* p : {st->G, st->H, st->a, st->b, st->gf, st->hf, st->Q, st->pts_tmp, st->sc_tmp, st->cLR, st->partial}) if (p) (void)hipFree(p);
+    for (void* p : {st->G, st->H, st->a, st->b, st->gf, st->hf, st->Q, st->pts_tmp, st->sc_tmp, st->cLR, st->partial, st->Pall, st->cG, st->cH, st->sL,
+                    st->sR}) if (p) (void)hipFree(p);
     delete st;
     return BP_OK;
 }
@@ -374,21 +397,15 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     if (!st) return BP_ERR_DEVICE;
     memset(st, 0, sizeof *st);
     st->ctx = ctx; st->n0 = st->n = n; st->first = true;
-    size_t blk = n + 1;   // 2h + 1 terms per MSM, two MSMs
-    bool ok = hipMalloc(&st->G, n * pt) == hipSuccess && hipMalloc(&st->H, n * pt) == hipSuccess && hipMalloc(&st->a, n * 32) == hipSuccess &&
-              hipMalloc(&st->b, n * 32) == hipSuccess && hipMalloc(&st->gf, n * 32) == hipSuccess && hipMalloc(&st->hf, n * 32) == hipSuccess &&
-              hipMalloc(&st->Q, pt) == hipSuccess && hipMalloc(&st->pts_tmp, 2 * blk * pt) == hipSuccess &&
-              hipMalloc(&st->sc_tmp, 2 * blk * 32) == hipSuccess && hipMalloc(&st->cLR, 64) == hipSuccess &&
-              hipMalloc(&st->partial, (kInnerBlocks + 1) * 32) == hipSuccess;
+    st->fold_generators = ctx->ipp_fold_generators;
     hipStream_t s = ctx->stream;
-    ok = ok && hipMemcpyAsync(st->G, G->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&                       // clones, ipp.rs:57-60
-         hipMemcpyAsync(st->H, H->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(st->a, a->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(st->b, b->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(st->gf, Gf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(st->hf, Hf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    bool ok = hipMalloc(&st->a, n * 32) == hipSuccess && hipMalloc(&st->b, n * 32) == hipSuccess && hipMalloc(&st->cLR, 64) == hipSuccess &&
+              hipMalloc(&st->partial, (kInnerBlocks + 1) * 32) == hipSuccess && hipMalloc(&st->Q, pt) == hipSuccess &&
+              hipMalloc(&st->pts_tmp, 2 * (n + 1) * pt) == hipSuccess;
+    ok = ok && hipMemcpyAsync(st->a, a->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&                       // clones, ipp.rs:57-60
+         hipMemcpyAsync(st->b, b->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess;
     if (ok) {
-        // Q: host bytes -> resident form (reuse pts_tmp as the raw staging area)
+        // Q: host bytes -> resident form (pts_tmp doubles as the raw staging area)
         ok = hipMemcpyAsync(st->pts_tmp, Q_le, pt, hipMemcpyHostToDevice, s) == hipSuccess;
         if (ok) {
             if (ctx->curve == BP_CURVE_BLS12_381)
@@ -398,12 +415,38 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
             ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         }
     }
+    if (ok && st->fold_generators) {
+        // reference-shaped mode: working copies of G, H are folded in place every round (k_ipp_fold)
+        ok = hipMalloc(&st->G, n * pt) == hipSuccess && hipMalloc(&st->H, n * pt) == hipSuccess && hipMalloc(&st->gf, n * 32) == hipSuccess &&
+             hipMalloc(&st->hf, n * 32) == hipSuccess && hipMalloc(&st->sc_tmp, 2 * (n + 1) * 32) == hipSuccess &&
+             hipMemcpyAsync(st->G, G->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(st->H, H->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(st->gf, Gf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(st->hf, Hf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    } else if (ok) {
+        // default: [G | H | Q] resident and never modified; coefficients start as the factors
+        size_t m = 2 * n + 1;
+        ok = hipMalloc(&st->Pall, m * pt) == hipSuccess && hipMalloc(&st->cG, n * 32) == hipSuccess && hipMalloc(&st->cH, n * 32) == hipSuccess &&
+             hipMalloc(&st->sL, m * 32) == hipSuccess && hipMalloc(&st->sR, m * 32) == hipSuccess &&
+             hipMemcpyAsync(st->Pall, G->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync((uint8_t*)st->Pall + n * pt, H->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync((uint8_t*)st->Pall + 2 * n * pt, st->Q, pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(st->cG, Gf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(st->cH, Hf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    }
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { bp_ipp_state_free(st); return BP_ERR_DEVICE; }
     *out = st;
     return BP_OK;
 }
 
 size_t bp_ipp_state_len(const bp_ipp_state* st) { return st ? st->n : 0; }
+
+int bp_ctx_set_ipp_fold_generators(bp_ctx* ctx, int on) {
+    if (!ctx) return BP_ERR_ARG;
+    ctx->ipp_fold_generators = on != 0;
+    return BP_OK;
+}
 
 int bp_ipp_round(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
     if (!st || !L_le || !R_le || st->n < 2) return BP_ERR_ARG;

@@ -189,6 +189,63 @@ __global__ void __launch_bounds__(kBlock) k_ipp_fold(AffPacked<C>* __restrict__ 
     V[i] = aff_pack(xyzz_to_aff<C>(r));
 }
 
+// ---------------------------------------------------------------------------------------------- IPP without folding generators
+// The folded generators are never needed for their own sake: after j rounds (current length nj = n0 >> j)
+//   G^(j)_i = sum over original k with (k mod nj) == i of cG_k * G_k ,   cG_k = Gf_k * prod_t (u_t^-1 or u_t by the bit of k
+// that picked the half at round t), and likewise H with cH_k (inverse choice).  Hence each round's
+//   L = <a_L, G_R> + <b_R, H_L> + c_L Q   and   R = <a_R, G_L> + <b_L, H_R> + c_R Q      (src/ipp.rs:148-170)
+// are MSMs over the ORIGINAL, resident [G | H | Q] with these scalars (zero where a generator does not take part):
+//   L:  G_k, pos >= h: a[pos - h] cG_k     H_k, pos <  h: b[h + pos] cH_k     Q: c_L          (pos = k mod nj, h = nj / 2)
+//   R:  G_k, pos <  h: a[h + pos] cG_k     H_k, pos >= h: b[pos - h] cH_k     Q: c_R
+// and the per-round "fold" is four Fr multiplications per generator instead of a 255-step double-scalar multiplication
+// (the reference's dominant cost, and on a GPU a ~10 ms serial chain per round).  Identical L, R, a, b.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_ipp_round_scalars(const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b,
+                                                              const ScalarWords* __restrict__ cG, const ScalarWords* __restrict__ cH,
+                                                              const ScalarWords* __restrict__ cLR, size_t n0, size_t nj,
+                                                              ScalarWords* __restrict__ sL, ScalarWords* __restrict__ sR) {
+    using F = typename C::Fr;
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n0) {
+        size_t h = nj / 2, pos = k & (nj - 1);
+        ScalarWords zero;
+        for (int i = 0; i < 8; i++) zero.w[i] = 0;
+        // canonical * canonical / R, then * R^2 / R  ->  canonical product
+        if (pos >= h) {
+            fr_store<F>(sL, k, fe_to_mont<F>(fe_mul(fr_load<F>(a, pos - h), fr_load<F>(cG, k))));
+            sR[k] = zero;
+            sL[n0 + k] = zero;
+            fr_store<F>(sR, n0 + k, fe_to_mont<F>(fe_mul(fr_load<F>(b, pos - h), fr_load<F>(cH, k))));
+        } else {
+            sL[k] = zero;
+            fr_store<F>(sR, k, fe_to_mont<F>(fe_mul(fr_load<F>(a, h + pos), fr_load<F>(cG, k))));
+            fr_store<F>(sL, n0 + k, fe_to_mont<F>(fe_mul(fr_load<F>(b, h + pos), fr_load<F>(cH, k))));
+            sR[n0 + k] = zero;
+        }
+    }
+    if (k == 0) { sL[2 * n0] = cLR[0]; sR[2 * n0] = cLR[1]; }
+}
+
+// cG_k *= (pos < h ? u^-1 : u); cH_k *= (pos < h ? u : u^-1); a, b folded (src/ipp.rs:116-129, 182-187).
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_ipp_fold_scalars(ScalarWords* __restrict__ a, ScalarWords* __restrict__ b, ScalarWords* __restrict__ cG,
+                                                             ScalarWords* __restrict__ cH, ScalarWords u_mont, ScalarWords uinv_mont, size_t n0,
+                                                             size_t nj) {
+    using F = typename C::Fr;
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n0) return;
+    Fe<F> u = fe_unpack_words<F>(u_mont.w), ui = fe_unpack_words<F>(uinv_mont.w);
+    size_t h = nj / 2, pos = k & (nj - 1);
+    bool left = pos < h;
+    fr_store<F>(cG, k, fe_mul(fr_load<F>(cG, k), left ? ui : u));
+    fr_store<F>(cH, k, fe_mul(fr_load<F>(cH, k), left ? u : ui));
+    if (k < h) {
+        Fe<F> aL = fr_load<F>(a, k), aR = fr_load<F>(a, h + k), bL = fr_load<F>(b, k), bR = fr_load<F>(b, h + k);
+        fr_store<F>(a, k, fe_add(fe_mul(aL, u), fe_mul(ui, aR)));
+        fr_store<F>(b, k, fe_add(fe_mul(bL, ui), fe_mul(u, bR)));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- IPP verification
 // Terms of the single verification MSM (src/ipp.rs:220-249): for i < n
 //   sc[1 + i]     = a * s_i * Gf_i         with  s_i = prod_j u_j^(+1 if bit (lg_n-1-j) of i else -1)     (:303-312)

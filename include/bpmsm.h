@@ -169,6 +169,12 @@ int bp_transcript_challenge_scalar(bp_transcript* t, int curve_id, const char* l
  * state_create enforces create_ipp's assertions (src/ipp.rs:48-55): n a power of two, all six lengths equal ->
  * BP_ERR_ARG otherwise. */
 typedef struct bp_ipp_state bp_ipp_state;
+/* Prover strategy for states created afterwards on this context.  0 (default): the generators are never folded --
+ * each round's L and R are MSMs over the original resident [G | H | Q] with per-generator coefficient vectors (four Fr
+ * multiplications per generator per round).  1: the reference's shape -- G and H are folded in place every round by a
+ * batched G1::binary_scalar_mul kernel (src/ipp.rs:119,125,185,187), a 255-step serial chain per element.  Both give
+ * bit-identical L, R, a, b. */
+int bp_ctx_set_ipp_fold_generators(bp_ctx* ctx, int on);
 int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* Q_le, const bp_frvec* G_factors,
                         const bp_frvec* H_factors, const bp_frvec* a, const bp_frvec* b, bp_ipp_state** out);
 size_t bp_ipp_state_len(const bp_ipp_state* st);

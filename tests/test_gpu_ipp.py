@@ -68,8 +68,18 @@ def load_case(bp, ctx, c):
     return n, Gv, Hv, Gf, Hf, a, b
 
 
+@pytest.fixture(params=[0, 1], ids=["msm-over-originals", "fold-generators"])
+def prover_mode(request, ctxs):
+    """Both prover strategies (include/bpmsm.h: bp_ctx_set_ipp_fold_generators) must give bit-identical proofs."""
+    for c in ctxs.values():
+        c.set_ipp_fold_generators(request.param)
+    yield request.param
+    for c in ctxs.values():
+        c.set_ipp_fold_generators(0)
+
+
 @pytest.mark.parametrize("name", CURVES)
-def test_ipp_golden_create_and_verify(bp, ctxs, golden, name):
+def test_ipp_golden_create_and_verify(bp, ctxs, golden, name, prover_mode):
     """Includes the reference's own two unit tests (src/ipp.rs:325-390 n=4, :393-489 n=8 padded) as fixtures."""
     ctx = ctxs[name]
     for c in golden("ipp")[name]:
@@ -131,7 +141,7 @@ def commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b):
 
 
 @pytest.mark.parametrize("name,n,unit_gf", [("bls12_381", 64, True), ("bls12_381", 32, False), ("bn254", 64, True), ("bn254", 256, False)])
-def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf):
+def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf, prover_mode):
     """BASELINE config 1 shape (n = 64): GPU proof bit-for-bit equal to the oracle's, accepted by both verifiers."""
     ctx = ctxs[name]
     cid = ctx.curve
@@ -148,7 +158,7 @@ def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf):
 
 
 @pytest.mark.parametrize("name", CURVES)
-def test_ipp_round_api_with_external_transcript(bp, ctxs, name):
+def test_ipp_round_api_with_external_transcript(bp, ctxs, name, prover_mode):
     """The low-level state API driven by a transcript the caller owns (here: the oracle's), as a Rust host would."""
     ctx = ctxs[name]
     cid = ctx.curve
