@@ -88,6 +88,7 @@ SYMBOLS = {
     "bp_frvec_wrap_device": (_I, [_P, _P, _SZ, _PP]),
     "bp_msm_g1": (_I, [_P, _P, _P, _U8P]),
     "bp_msm_g1_range": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _U8P]),
+    "bp_msm_g1_pair": (_I, [_P, _P, _P, _P, _U8P, _U8P]),
     "bp_msm_window_records": (_SZ, [_P, _SZ]),
     "bp_msm_record_bytes": (_SZ, [_I]),
     "bp_msm_g1_windows": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _P]),
@@ -98,6 +99,9 @@ SYMBOLS = {
     "bp_fr_scaled_by": (_I, [_P, _P, _U8P, _PP]),
     "bp_fr_vandermonde": (_I, [_P, _U8P, _SZ, _PP]),
     "bp_fr_inverse": (_I, [_I, _U8P, _U8P]),
+    "bp_vecpoly3_special_inner_product": (_I, [_P, _PP, _PP, _U8P]),
+    "bp_vecpoly1_inner_product": (_I, [_P, _PP, _PP, _U8P]),
+    "bp_vecpoly_eval": (_I, [_P, _PP, _I, _U8P, _PP]),
     "bp_transcript_new": (_I, [_U8P, _SZ, _PP]),
     "bp_transcript_free": (_I, [_P]),
     "bp_transcript_append_message": (_I, [_P, _U8P, _SZ, _U8P, _SZ]),
@@ -265,6 +269,12 @@ class G1Vector:
 
     inner_product_var_time = multi_scalar_mul_var_time
     inner_product_const_time = multi_scalar_mul_var_time
+
+    def multi_scalar_mul_pair(self, scalars1, scalars2):
+        """(<s1, P>, <s2, P>) in one pipeline pass"""
+        o1, o2 = ctypes.create_string_buffer(self.ctx.point_bytes), ctypes.create_string_buffer(self.ctx.point_bytes)
+        _check(lib().bp_msm_g1_pair(self.ctx.h, self.h, scalars1.h, scalars2.h, o1, o2), "bp_msm_g1_pair")
+        return o1.raw, o2.raw
 
     def msm_range(self, poff, scalars, soff, n):
         out = ctypes.create_string_buffer(self.ctx.point_bytes)
@@ -518,3 +528,53 @@ class IPP:
                       ctypes.create_string_buffer(max(1, n) * 32))
         _check(lib().bp_ipp_verification_scalars(curve, transcript.h, bytes(L_le), bytes(R_le), lg_n, n, us, uis, s), "bp_ipp_verification_scalars")
         return us.raw[: lg_n * 32], uis.raw[: lg_n * 32], s.raw[: n * 32]
+
+
+# ---- vector polynomials (src/utils/vector_poly.rs) -------------------------------------------------------------------
+
+def _handles(vs):
+    arr = (ctypes.c_void_p * len(vs))()
+    for i, v in enumerate(vs):
+        arr[i] = v.h
+    return arr
+
+
+class VecPoly1:
+    """A + B*X"""
+
+    def __init__(self, a, b):
+        self.v = (a, b)
+
+    def inner_product(self, rhs):
+        """-> Poly2 coefficients (t0, t1, t2) as 32-byte LE scalars"""
+        ctx = self.v[0].ctx
+        out = ctypes.create_string_buffer(96)
+        _check(lib().bp_vecpoly1_inner_product(ctx.h, _handles(self.v), _handles(rhs.v), out), "bp_vecpoly1_inner_product")
+        return out.raw[:32], out.raw[32:64], out.raw[64:96]
+
+    def eval(self, x_le32):
+        ctx = self.v[0].ctx
+        h = ctypes.c_void_p()
+        _check(lib().bp_vecpoly_eval(ctx.h, _handles(self.v), 1, bytes(x_le32), ctypes.byref(h)), "bp_vecpoly_eval")
+        return FieldElementVector(ctx, h)
+
+
+class VecPoly3:
+    """A + B*X + C*X^2 + D*X^3"""
+
+    def __init__(self, a, b, c, d):
+        self.v = (a, b, c, d)
+
+    @staticmethod
+    def special_inner_product(lhs, rhs):
+        """-> Poly6 coefficients (t1..t6); requires lhs.0 == 0 and rhs.2 == 0 (src/utils/vector_poly.rs:75-79)"""
+        ctx = lhs.v[0].ctx
+        out = ctypes.create_string_buffer(192)
+        _check(lib().bp_vecpoly3_special_inner_product(ctx.h, _handles(lhs.v), _handles(rhs.v), out), "bp_vecpoly3_special_inner_product")
+        return [out.raw[32 * i:32 * i + 32] for i in range(6)]
+
+    def eval(self, x_le32):
+        ctx = self.v[0].ctx
+        h = ctypes.c_void_p()
+        _check(lib().bp_vecpoly_eval(ctx.h, _handles(self.v), 3, bytes(x_le32), ctypes.byref(h)), "bp_vecpoly_eval")
+        return FieldElementVector(ctx, h)

@@ -16,7 +16,7 @@ struct MsmGeom {
     uint32_t bpw;    // reduce blocks per window (max over windows)
 };
 
-static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
+static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1) {
     int c = c_override;
     if (c <= 0) {
         int lg = 0;
@@ -27,16 +27,20 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
     if (c > 16) c = 16;
     g.c = c;
     int cover = fr_bits + 1;
-    int W = (cover + c - 1) / c;
-    int base = cover / W, extra = cover % W;     // `extra` windows of base+1 bits, the rest base bits (all <= c)
+    int W1 = (cover + c - 1) / c;                 // windows per scalar set
+    int base = cover / W1, extra = cover % W1;    // `extra` windows of base+1 bits, the rest base bits (all <= c)
     WinTab& t = g.tab;
     memset(&t, 0, sizeof t);
+    const int W = W1 * nsets;
     t.W = W;
+    t.nsets = nsets;
     uint32_t bias[8] = {0};
     int off = 0;
     uint32_t nb = 0, maxB = 0, rows = 0;
     for (int w = 0; w < W; w++) {
-        int cw = base + (w < extra ? 1 : 0);
+        const int w1 = w % W1;
+        if (w1 == 0) off = 0;
+        int cw = base + (w1 < extra ? 1 : 0);
         t.cw[w] = (uint8_t)cw;
         t.off[w] = (uint16_t)off;
         t.boff[w] = nb;
@@ -47,6 +51,7 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override) {
         uint32_t B = 1u << (cw - 1);
         nb += B;
         if (B > maxB) maxB = B;
+        if (w >= W1) { off += cw; continue; }     // the bias is per scalar: accumulate it over the first set only
         // bias += (2^(cw-1) - 1) << off
         uint64_t half1 = (uint64_t)B - 1;
         int word = off >> 5, sh = off & 31;
@@ -89,8 +94,8 @@ struct Impl {
     }
 
     // Device stage: window sums of  sum_i s_i P_i  into ctx->window_sum (W records).
-    static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g) {
-        msm_geom(g, C::Fr::BITS, n, ctx->c_override);
+    static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g, const ScalarWords* sc2 = nullptr) {
+        msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1);
         const WinTab& tab = g.tab;
         const int W = tab.W;
         if (getenv("BP_TRACE")) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d nbuckets=%u m=%u bpw=%u\n", n, g.c, W, tab.nbuckets, g.m, g.bpw);
@@ -153,7 +158,7 @@ struct Impl {
         uint32_t* tile_hist = (uint32_t*)ctx->tile_hist.p;
         uint16_t* tmp_code = (uint16_t*)ctx->tmp_code.p;
         uint32_t* tmp_idx = (uint32_t*)ctx->tmp_idx.p;
-        hipLaunchKernelGGL(k_digits_bin, dim3(ntiles), dim3(kBlock), 0, st, sc, n, tab, ntiles, code, tile_hist);
+        hipLaunchKernelGGL(k_digits_bin, dim3(ntiles), dim3(kBlock), 0, st, sc, sc2, n, tab, ntiles, code, tile_hist);
         BP_TRACE_SYNC(ctx, "k_digits_bin");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, bsum);
@@ -247,6 +252,22 @@ struct Impl {
         return BP_OK;
     }
 
+    // Two scalar sets over the same points in ONE pipeline pass (2W windows): out1 = <sc1, pts>, out2 = <sc2, pts>.
+    static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le) {
+        if (n == 0) { memset(out1_le, 0, 2 * 4 * Fp::NW); memset(out2_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
+        MsmGeom g;
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2);
+        if (rc) return rc;
+        const int W = g.tab.W, W1 = W / 2;
+        if ((rc = host_pinned_reserve(ctx, (size_t)W * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        collect_timing(ctx);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, W1, g.tab.cw, out1_le);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned + W1, 1, W1, g.tab.cw + W1, out2_le);
+        return BP_OK;
+    }
+
     static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
@@ -314,6 +335,10 @@ int bp_internal_set_device(const bp_ctx* ctx) { return set_device(ctx); }
 
 int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le) {
     DISPATCH(ctx, I::msm(ctx, points, 0, scalars, 0, n, out_le));
+}
+
+int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le) {
+    DISPATCH(ctx, I::msm2(ctx, points, scalars1, scalars2, n, out1_le, out2_le));
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -568,6 +593,13 @@ int bp_msm_g1(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars, uint
     if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
     if (points->n != scalars->n) return BP_ERR_LENGTH;
     return bp_msm_g1_range(ctx, points, 0, scalars, 0, points->n, out_le);
+}
+
+int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1, const bp_frvec* scalars2, uint8_t* out1_le, uint8_t* out2_le) {
+    if (!ctx || !points || !scalars1 || !scalars2 || !out1_le || !out2_le) return BP_ERR_ARG;
+    if (points->n != scalars1->n || points->n != scalars2->n) return BP_ERR_LENGTH;
+    int rc = set_device(ctx); if (rc) return rc;
+    return bp_internal_msm2(ctx, points->d, scalars1->d, scalars2->d, points->n, out1_le, out2_le);
 }
 
 size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {

@@ -107,9 +107,7 @@ struct Ipp {
                                (const ScalarWords*)st->cH, cLR, st->n0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
-            if ((rc = bp_internal_msm(ctx, st->Pall, st->sL, m, L_le))) return rc;
-            if ((rc = bp_internal_msm(ctx, st->Pall, st->sR, m, R_le))) return rc;
-            return BP_OK;
+            return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le);   // both sums in one pipeline pass
         }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
                            (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,
@@ -369,6 +367,89 @@ int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** o
         hipLaunchKernelGGL(k_fr_vandermonde<Bls381>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, fr_mont_words<Bls381Fr>(fr_from_le<Bls381Fr>(e_le32)), n, (ScalarWords*)(*out)->d);
     else
         hipLaunchKernelGGL(k_fr_vandermonde<Bn254>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(e_le32)), n, (ScalarWords*)(*out)->d);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+// ---- vector polynomials (src/utils/vector_poly.rs) ----------------------------------------------------------
+static int same_len(const bp_frvec* const* v, int k, size_t* n) {
+    for (int i = 0; i < k; i++) if (!v[i]) return BP_ERR_ARG;
+    *n = v[0]->n;
+    for (int i = 1; i < k; i++) if (v[i]->n != *n) return BP_ERR_LENGTH;
+    return BP_OK;
+}
+
+int bp_vecpoly3_special_inner_product(bp_ctx* ctx, const bp_frvec* const lhs[4], const bp_frvec* const rhs[4], uint8_t* out_t1_to_t6) {
+    if (!ctx || !lhs || !rhs || !out_t1_to_t6) return BP_ERR_ARG;
+    size_t n, n2;
+    int rc;
+    if ((rc = same_len(lhs, 4, &n)) || (rc = same_len(rhs, 4, &n2))) return rc;
+    if (n != n2) return BP_ERR_LENGTH;
+    if ((rc = bp_internal_set_device(ctx))) return rc;
+    if ((rc = ctx->scratch.reserve((6 * kInnerBlocks + 8) * 32))) return rc;
+    auto* out = (ScalarWords*)ctx->scratch.p;
+    auto* part = out + 8;
+    unsigned g = blocks_for(n);
+    if (g > kInnerBlocks) g = kInnerBlocks;
+    if (g == 0) g = 1;
+    auto L = [&](int i) { return (const ScalarWords*)lhs[i]->d; };
+    auto R = [&](int i) { return (const ScalarWords*)rhs[i]->d; };
+    if (ctx->curve == BP_CURVE_BLS12_381) {
+        hipLaunchKernelGGL(k_vecpoly3_special<Bls381>, dim3(g), dim3(kBlock), 0, ctx->stream, L(1), L(2), L(3), R(0), R(1), R(3), n, part);
+        hipLaunchKernelGGL(k_fr_multi_final<Bls381>, dim3(1), dim3(kBlock), 0, ctx->stream, part, g, 6u, out);
+    } else {
+        hipLaunchKernelGGL(k_vecpoly3_special<Bn254>, dim3(g), dim3(kBlock), 0, ctx->stream, L(1), L(2), L(3), R(0), R(1), R(3), n, part);
+        hipLaunchKernelGGL(k_fr_multi_final<Bn254>, dim3(1), dim3(kBlock), 0, ctx->stream, part, g, 6u, out);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_t1_to_t6, out, 6 * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+
+int bp_vecpoly1_inner_product(bp_ctx* ctx, const bp_frvec* const l[2], const bp_frvec* const r[2], uint8_t* out_t0_t1_t2) {
+    if (!ctx || !l || !r || !out_t0_t1_t2) return BP_ERR_ARG;
+    size_t n, n2;
+    int rc;
+    if ((rc = same_len(l, 2, &n)) || (rc = same_len(r, 2, &n2))) return rc;
+    if (n != n2) return BP_ERR_LENGTH;
+    if ((rc = bp_internal_set_device(ctx))) return rc;
+    if ((rc = ctx->scratch.reserve((3 * kInnerBlocks + 8) * 32))) return rc;
+    auto* out = (ScalarWords*)ctx->scratch.p;
+    auto* part = out + 8;
+    unsigned g = blocks_for(n);
+    if (g > kInnerBlocks) g = kInnerBlocks;
+    if (g == 0) g = 1;
+    if (ctx->curve == BP_CURVE_BLS12_381) {
+        hipLaunchKernelGGL(k_vecpoly1_inner<Bls381>, dim3(g), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)l[0]->d, (const ScalarWords*)l[1]->d,
+                           (const ScalarWords*)r[0]->d, (const ScalarWords*)r[1]->d, n, part);
+        hipLaunchKernelGGL(k_fr_multi_final<Bls381>, dim3(1), dim3(kBlock), 0, ctx->stream, part, g, 3u, out);
+    } else {
+        hipLaunchKernelGGL(k_vecpoly1_inner<Bn254>, dim3(g), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)l[0]->d, (const ScalarWords*)l[1]->d,
+                           (const ScalarWords*)r[0]->d, (const ScalarWords*)r[1]->d, n, part);
+        hipLaunchKernelGGL(k_fr_multi_final<Bn254>, dim3(1), dim3(kBlock), 0, ctx->stream, part, g, 3u, out);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_t0_t1_t2, out, 3 * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+
+int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uint8_t* x_le32, bp_frvec** out) {
+    if (!ctx || !p || !x_le32 || !out || (degree != 1 && degree != 3)) return BP_ERR_ARG;
+    size_t n;
+    int rc;
+    if ((rc = same_len(p, degree + 1, &n))) return rc;
+    if ((rc = alloc_frvec(ctx, n, out))) return rc;
+    if (n == 0) return BP_OK;
+    const ScalarWords* q[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i <= degree; i++) q[i] = (const ScalarWords*)p[i]->d;
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_vecpoly_eval<Bls381>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, q[0], q[1], q[2], q[3], degree,
+                           fr_mont_words<Bls381Fr>(fr_from_le<Bls381Fr>(x_le32)), n, (ScalarWords*)(*out)->d);
+    else
+        hipLaunchKernelGGL(k_vecpoly_eval<Bn254>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, q[0], q[1], q[2], q[3], degree,
+                           fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(x_le32)), n, (ScalarWords*)(*out)->d);
     HIPCHK(hipGetLastError());
     return BP_OK;
 }

@@ -97,6 +97,96 @@ __global__ void __launch_bounds__(kBlock) k_fr_vandermonde(ScalarWords e_mont, s
     fr_store<F>(out, i, fe_from_mont<F>(acc));
 }
 
+// ---------------------------------------------------------------------------------------------- vector polynomials
+// /root/reference src/utils/vector_poly.rs (R1CS t(x), l(x), r(x)).
+// VecPoly3::special_inner_product (:79-97): lhs.0 == 0 and rhs.2 == 0 by construction; the nine inner products are
+// fused into one pass over the six vectors that matter.  partial[(blockIdx.x * 6 + j)] = block sum of t_(j+1) / R.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_vecpoly3_special(const ScalarWords* __restrict__ l1, const ScalarWords* __restrict__ l2,
+                                                             const ScalarWords* __restrict__ l3, const ScalarWords* __restrict__ r0,
+                                                             const ScalarWords* __restrict__ r1, const ScalarWords* __restrict__ r3, size_t n,
+                                                             ScalarWords* __restrict__ partial) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    Fe<F> t[6];
+    for (int j = 0; j < 6; j++) t[j] = fe_zero<F>();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fe<F> a1 = fr_load<F>(l1, i), a2 = fr_load<F>(l2, i), a3 = fr_load<F>(l3, i);
+        Fe<F> b0 = fr_load<F>(r0, i), b1 = fr_load<F>(r1, i), b3 = fr_load<F>(r3, i);
+        t[0] = fe_add(t[0], fe_mul(a1, b0));
+        t[1] = fe_add(t[1], fe_add(fe_mul(a1, b1), fe_mul(a2, b0)));
+        t[2] = fe_add(t[2], fe_add(fe_mul(a2, b1), fe_mul(a3, b0)));
+        t[3] = fe_add(t[3], fe_add(fe_mul(a1, b3), fe_mul(a3, b1)));
+        t[4] = fe_add(t[4], fe_mul(a2, b3));
+        t[5] = fe_add(t[5], fe_mul(a3, b3));
+    }
+    for (int j = 0; j < 6; j++) {
+        Fe<F> s = block_fr_sum<F>(t[j], lds);
+        if (threadIdx.x == 0) fr_store<F>(partial, (size_t)blockIdx.x * 6 + j, s);
+        __syncthreads();
+    }
+}
+
+// single block: out[j] = R * sum_b partial[b * k + j], j < k  (k <= 6)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_multi_final(const ScalarWords* __restrict__ partial, uint32_t m, uint32_t k, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    for (uint32_t j = 0; j < k; j++) {
+        Fe<F> acc = fe_zero<F>();
+        for (uint32_t i = threadIdx.x; i < m; i += kBlock) acc = fe_add(acc, fr_load<F>(partial, (size_t)i * k + j));
+        acc = block_fr_sum<F>(acc, lds);
+        if (threadIdx.x == 0) fr_store<F>(out, j, fe_to_mont<F>(acc));
+        __syncthreads();
+    }
+}
+
+// VecPoly1::inner_product (:36-53): (t0, t1, t2) = (<l0,r0>, <l0,r1> + <l1,r0>, <l1,r1>)  (the reference's Karatsuba
+// form computes the same t1).
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_vecpoly1_inner(const ScalarWords* __restrict__ l0, const ScalarWords* __restrict__ l1,
+                                                           const ScalarWords* __restrict__ r0, const ScalarWords* __restrict__ r1, size_t n,
+                                                           ScalarWords* __restrict__ partial) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    Fe<F> t[3];
+    for (int j = 0; j < 3; j++) t[j] = fe_zero<F>();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fe<F> a0 = fr_load<F>(l0, i), a1 = fr_load<F>(l1, i), b0 = fr_load<F>(r0, i), b1 = fr_load<F>(r1, i);
+        t[0] = fe_add(t[0], fe_mul(a0, b0));
+        t[1] = fe_add(t[1], fe_add(fe_mul(a0, b1), fe_mul(a1, b0)));
+        t[2] = fe_add(t[2], fe_mul(a1, b1));
+    }
+    for (int j = 0; j < 3; j++) {
+        Fe<F> s = block_fr_sum<F>(t[j], lds);
+        if (threadIdx.x == 0) fr_store<F>(partial, (size_t)blockIdx.x * 3 + j, s);
+        __syncthreads();
+    }
+}
+
+// VecPoly3::eval (:99-106) / VecPoly1::eval (:55-62): Horner per element; deg = 3 or 1.  x_mont in Montgomery form.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_vecpoly_eval(const ScalarWords* __restrict__ p0, const ScalarWords* __restrict__ p1,
+                                                         const ScalarWords* __restrict__ p2, const ScalarWords* __restrict__ p3, int deg,
+                                                         ScalarWords x_mont, size_t n, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> x = fe_unpack_words<F>(x_mont.w);
+    Fe<F> acc;
+    if (deg == 3) {
+        acc = fr_load<F>(p3, i);
+        acc = fe_add(fr_load<F>(p2, i), fe_mul(acc, x));     // canonical * Montgomery x -> canonical
+        acc = fe_add(fr_load<F>(p1, i), fe_mul(acc, x));
+    } else {
+        acc = fr_load<F>(p1, i);
+    }
+    acc = fe_add(fr_load<F>(p0, i), fe_mul(acc, x));
+    fr_store<F>(out, i, acc);
+}
+
 // ---------------------------------------------------------------------------------------------- IPP round
 // Assemble the MSM terms of L and R for the current round of length n = 2h (src/ipp.rs:80-104 / :148-170):
 //   L: points [G_R | H_L | Q], scalars [a_L (.Gf_R) | b_R (.Hf_L) | c_L]

@@ -41,9 +41,10 @@ struct alignas(16) ScalarWords {
 // Window table: W windows of (nearly equal) widths cw[w] covering fr_bits + 1 bits, window w starting at bit
 // off[w]; window w owns buckets boff[w] .. boff[w+1]-1 (2^(cw-1) of them, bucket j <-> |digit| = j + 1).
 // Equal widths matter: a narrow top window would put n / 2^(few bits) points into each of its buckets.
-constexpr int kMaxWindows = 128;
+constexpr int kMaxWindows = 256;   // up to two scalar sets of 128 windows each
 struct WinTab {
-    int W;
+    int W;            // windows of ALL scalar sets (set s owns windows [s * W / nsets, (s + 1) * W / nsets))
+    int nsets;        // scalar sets sharing the same points (1 or 2)
     uint32_t nbuckets;
     uint8_t cw[kMaxWindows];
     uint16_t off[kMaxWindows];
@@ -54,7 +55,7 @@ struct WinTab {
 };
 
 constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane)
-constexpr int kMaxBinRows = 2048;      // sum over windows of coarse bins (c = 16: 16 x 128)
+constexpr int kMaxBinRows = 4096;      // sum over windows of coarse bins (c = 16: 16 x 128 per scalar set)
 
 // Signed-digit recoding without a serial carry: with k' = k + H, the raw cw-bit window w of k' equals
 // digit_w + (2^(cw-1) - 1), digit_w in [-(2^(cw-1) - 1), 2^(cw-1)], sum_w digit_w 2^off[w] = k.  (Adding
@@ -83,8 +84,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t
 //                  the 4-byte stores combine in L2 instead of costing a 64-byte write-back each.
 // (The first version -- global-atomic histogram + global random scatter -- took 0.63 + 1.48 ms at n = 2^20 with 1.0 GB
 // of WRITE_SIZE for 64 MB of useful output: profiles/r01_bench_n1_pmc_hbm.json.)
-static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords* __restrict__ scalars, size_t n, WinTab tab, uint32_t ntiles,
-                                                             uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
+static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords* __restrict__ scalars, const ScalarWords* __restrict__ scalars2, size_t n,
+                                                             WinTab tab, uint32_t ntiles, uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
     __shared__ uint32_t lh[kMaxBinRows];
     const uint32_t rows = tab.hoff[tab.W];
     for (uint32_t k = threadIdx.x; k < rows; k += kBlock) lh[k] = 0;
@@ -94,18 +95,21 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
     for (int e = 0; e < kTile / kBlock; e++) {
         size_t i = base + (size_t)e * kBlock + threadIdx.x;
         if (i < n) {
-            uint64_t q[4];
-            add256(q, scalars[i], tab.bias);
-            for (int w = 0; w < tab.W; w++) {
-                int c = tab.cw[w];
-                uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);
-                q[0] = (q[0] >> c) | (q[1] << (64 - c));
-                q[1] = (q[1] >> c) | (q[2] << (64 - c));
-                q[2] = (q[2] >> c) | (q[3] << (64 - c));
-                q[3] >>= c;
-                code[(size_t)w * n + i] = (uint16_t)raw;
-                int d = (int)raw - ((1 << (c - 1)) - 1);
-                if (d != 0) atomicAdd(&lh[tab.hoff[w] + (((uint32_t)(d < 0 ? -d : d) - 1) >> tab.fbits[w])], 1u);
+            const int wps = tab.W / tab.nsets;   // windows per scalar set (same geometry for every set)
+            for (int set = 0; set < tab.nsets; set++) {
+                uint64_t q[4];
+                add256(q, set ? scalars2[i] : scalars[i], tab.bias);
+                for (int w = set * wps; w < (set + 1) * wps; w++) {
+                    int c = tab.cw[w];
+                    uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);
+                    q[0] = (q[0] >> c) | (q[1] << (64 - c));
+                    q[1] = (q[1] >> c) | (q[2] << (64 - c));
+                    q[2] = (q[2] >> c) | (q[3] << (64 - c));
+                    q[3] >>= c;
+                    code[(size_t)w * n + i] = (uint16_t)raw;
+                    int d = (int)raw - ((1 << (c - 1)) - 1);
+                    if (d != 0) atomicAdd(&lh[tab.hoff[w] + (((uint32_t)(d < 0 ? -d : d) - 1) >> tab.fbits[w])], 1u);
+                }
             }
         }
     }
@@ -354,11 +358,15 @@ __global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* 
 
 // ---------------------------------------------------------------------------------------------- bucket reduce
 // LDS tree over the block's kBlock partial sums (packed, 4*NW words each); result valid in thread 0.
+// `active` = number of leading threads that can hold a non-identity value (the tree starts at the first power of two
+// that covers them: small MSMs have a handful of segments per window, not 256).
 template <class C>
-__device__ __forceinline__ Xyzz<C> block_tree_sum(Xyzz<C> mine, XyzzPacked<C>* lds) {
+__device__ __forceinline__ Xyzz<C> block_tree_sum(Xyzz<C> mine, XyzzPacked<C>* lds, int active = kBlock) {
     lds[threadIdx.x] = xyzz_pack(mine);
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
+    int s0 = kBlock / 2;
+    while (s0 >= active && s0 > 0) s0 >>= 1;   // largest stride with a live partner
+    for (int s = s0; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             mine = xyzz_add(mine, xyzz_unpack(lds[threadIdx.x + s]));
             lds[threadIdx.x] = xyzz_pack(mine);
@@ -431,7 +439,8 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
         }
         mine = xyzz_add(tri, xyzz_mul_small<C>(lo, run));
     }
-    mine = block_tree_sum<C>(mine, lds);
+    uint32_t live = T - blockIdx.x * kBlock;
+    mine = block_tree_sum<C>(mine, lds, live < (uint32_t)kBlock ? (int)live : kBlock);
     if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = xyzz_pack(mine);
 }
 
@@ -443,7 +452,7 @@ __global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __r
     uint32_t w = blockIdx.x;
     Xyzz<C> mine = xyzz_inf<C>();
     for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_add(mine, xyzz_unpack(partial[(size_t)w * per_window + j]));
-    mine = block_tree_sum<C>(mine, lds);
+    mine = block_tree_sum<C>(mine, lds, per_window < (uint32_t)kBlock ? (int)per_window : kBlock);
     if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
 }
 

@@ -115,6 +115,10 @@ int bp_msm_g1(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars, uint
  * BP_ERR_LENGTH if a range overruns its vector. */
 int bp_msm_g1_range(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n,
                     uint8_t* out_le);
+/* Two scalar vectors over the SAME points in one pipeline pass (twice the windows, one set of launches, one D2H):
+ * out1 = <scalars1, points>, out2 = <scalars2, points>.  The IPP prover's L and R of a round are such a pair
+ * (src/ipp.rs:148-170), as are commitments that share the generator vector (src/r1cs/prover.rs:347-362). */
+int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1, const bp_frvec* scalars2, uint8_t* out1_le, uint8_t* out2_le);
 /* Two-stage form used when the index range is sharded over several GPUs (one process per GPU).
  * Stage 1 (device): each rank runs the bucket pipeline on its own slice and leaves its W per-window bucket sums
  * ("window records", un-normalised XYZZ, bp_msm_record_bytes() each, bp_msm_window_records(ctx, n) of them) in a
@@ -144,6 +148,13 @@ int bp_fr_hadamard(bp_ctx* ctx, const bp_frvec* a, const bp_frvec* b, bp_frvec**
 int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_frvec** out);
 /* FieldElementVector::new_vandermonde_vector(e, n) = [1, e, e^2, ...] (src/ipp.rs:348; src/r1cs/prover.rs:463). */
 int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** out);
+/* VecPoly3::special_inner_product (src/utils/vector_poly.rs:79-97): lhs = (0, l1, l2, l3), rhs = (r0, r1, 0, r3);
+ * writes t1..t6 (6 x 32-byte LE).  lhs[0] and rhs[2] are not read.  One fused pass instead of nine inner products. */
+int bp_vecpoly3_special_inner_product(bp_ctx* ctx, const bp_frvec* const lhs[4], const bp_frvec* const rhs[4], uint8_t* out_t1_to_t6);
+/* VecPoly1::inner_product (src/utils/vector_poly.rs:36-53): Poly2 (t0, t1, t2), 3 x 32-byte LE. */
+int bp_vecpoly1_inner_product(bp_ctx* ctx, const bp_frvec* const l[2], const bp_frvec* const r[2], uint8_t* out_t0_t1_t2);
+/* VecPoly1::eval / VecPoly3::eval (src/utils/vector_poly.rs:55-62, 99-106): out[i] = sum_d p[d][i] x^d, degree 1 or 3. */
+int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uint8_t* x_le32, bp_frvec** out);
 /* FieldElement::inverse (src/ipp.rs:113,179); host arithmetic, no GPU needed; inverse of 0 is 0. */
 int bp_fr_inverse(int curve_id, const uint8_t* in_le32, uint8_t* out_le32);
 

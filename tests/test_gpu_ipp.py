@@ -56,6 +56,35 @@ def test_fr_vector_kernels(bp, ctxs, name):
         ((r - 1 + (r - 1) * (r - 1)) % r).to_bytes(32, "little")
 
 
+@pytest.mark.parametrize("name", CURVES)
+def test_vector_poly_kernels(bp, ctxs, name):
+    """src/utils/vector_poly.rs: VecPoly1/3 inner products and evals against Python-int arithmetic."""
+    ctx = ctxs[name]
+    r = ctx.r
+    for n in (1, 300, 4099):
+        vecs = [ints(O.random_scalars(ctx.curve, 900 + 10 * n + j, n)) for j in range(8)]
+        dev = [bp.FieldElementVector.from_ints(ctx, v) for v in vecs]
+        zero = bp.FieldElementVector.new(ctx, n)
+        l, rr = vecs[0:4], vecs[4:8]
+        lhs = bp.VecPoly3(zero, dev[1], dev[2], dev[3])
+        rhs = bp.VecPoly3(dev[4], dev[5], zero, dev[7])
+        ip = lambda a, b: sum(x * y for x, y in zip(a, b)) % r
+        want = [ip(l[1], rr[0]), (ip(l[1], rr[1]) + ip(l[2], rr[0])) % r, (ip(l[2], rr[1]) + ip(l[3], rr[0])) % r,
+                (ip(l[1], rr[3]) + ip(l[3], rr[1])) % r, ip(l[2], rr[3]), ip(l[3], rr[3])]
+        got = [int.from_bytes(t, "little") for t in bp.VecPoly3.special_inner_product(lhs, rhs)]
+        assert got == want
+        x = vecs[0][0]
+        xb = x.to_bytes(32, "little")
+        p3 = bp.VecPoly3(dev[0], dev[1], dev[2], dev[3])
+        assert ints(p3.eval(xb).to_bytes()) == [(a + x * (b + x * (c + x * d))) % r for a, b, c, d in zip(*vecs[0:4])]
+        p1a, p1b = bp.VecPoly1(dev[0], dev[1]), bp.VecPoly1(dev[4], dev[5])
+        assert ints(p1a.eval(xb).to_bytes()) == [(a + b * x) % r for a, b in zip(vecs[0], vecs[1])]
+        t0, t1, t2 = (int.from_bytes(t, "little") for t in p1a.inner_product(p1b))
+        assert (t0, t1, t2) == (ip(vecs[0], vecs[4]), (ip(vecs[0], vecs[5]) + ip(vecs[1], vecs[4])) % r, ip(vecs[1], vecs[5]))
+    with pytest.raises(bp.ValueError_):
+        bp.VecPoly1(dev[0], bp.FieldElementVector.from_ints(ctx, [1, 2])).eval(xb)
+
+
 def load_case(bp, ctx, c):
     n = c["n"]
     cat = lambda k: b"".join(hx(x) for x in c[k])

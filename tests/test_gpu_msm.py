@@ -120,6 +120,23 @@ def test_msm_random_vs_oracle(bp, ctxs, name, n):
 
 
 @pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("n", [1, 3, 129, 5000, 70000])
+def test_msm_pair_equals_two_msms(bp, ctxs, name, n):
+    ctx = ctxs[name]
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, O.random_scalars(ctx.curve, 50 + n, n), n))
+    s1b = O.random_scalars(ctx.curve, 60 + n, n)
+    s2b = bytes(32) * (n // 2) + O.random_scalars(ctx.curve, 70 + n, n - n // 2)      # half zeros, like the IPP's L/R scalars
+    s1, s2 = bp.FieldElementVector.from_bytes(ctx, s1b, n), bp.FieldElementVector.from_bytes(ctx, s2b, n)
+    host = pts.to_bytes()
+    got = pts.multi_scalar_mul_pair(s1, s2)
+    assert got[0] == O.msm(ctx.curve, host, s1b, n, algo=O.PIPPENGER, nthreads=8)
+    assert got[1] == O.msm(ctx.curve, host, s2b, n, algo=O.PIPPENGER, nthreads=8)
+    assert got == (pts.multi_scalar_mul_var_time(s1), pts.multi_scalar_mul_var_time(s2))
+    with pytest.raises(bp.ValueError_):
+        pts.multi_scalar_mul_pair(s1, bp.FieldElementVector.from_ints(ctx, [1] * (n + 1)))
+
+
+@pytest.mark.parametrize("name", CURVES)
 def test_msm_skewed_scalars(bp, ctxs, name):
     """config-3-like inputs: bit scalars, all-equal scalars, 1% zeros -- heavy single buckets."""
     ctx = ctxs[name]
