@@ -61,8 +61,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # Launched by torch.distributed.run (even with one rank): go through RCCL so that the sharded path is the one
+    # that runs.  A plain `python bench.py` is the single-GPU path with no process group.
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -91,14 +95,14 @@ def main():
     mine = torch.zeros(W * rb, dtype=torch.uint8, device=dev)
 
     def step():
-        if world == 1:
+        if not use_dist:
             return pts.multi_scalar_mul_var_time(sv)
         bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
         allrec = sharding.all_gather_records(mine, world)          # RCCL all_gather_into_tensor
         return bp.msm_finish(ctx, allrec.data_ptr(), world, n)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -110,7 +114,7 @@ def main():
         result = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -164,7 +168,7 @@ def main():
             "config": {"workload": "2^%d-point %s G1 Pippenger MSM per GPU, uniform random scalars, points k_i*G, inputs resident in HBM"
                                    % (args.lg_n, args.curve),
                        "curve": args.curve, "n_per_gpu": n, "n_total": total_units, "windows": int(W),
-                       "sharding": "index range per rank, all_gather of %d window records/rank over RCCL" % W if world > 1 else "single GPU"},
+                       "sharding": "index range per rank, all_gather of %d window records/rank over RCCL" % W if use_dist else "single GPU"},
             "stages_ms": stages,
             "roofline": roofline,
         }
@@ -204,7 +208,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

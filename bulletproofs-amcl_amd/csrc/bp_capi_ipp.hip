@@ -28,6 +28,7 @@ struct bp_ipp_state {
     // default mode (generators never folded, see bp_ipp.cuh): resident [G | H | Q], coefficient vectors, L/R scalars
     bool fold_generators;
     void *Pall, *cG, *cH, *sL, *sR;
+    int device;
 };
 
 namespace {
@@ -457,8 +458,7 @@ int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uin
 // ---- IPP device-resident state ------------------------------------------------------------------------------
 int bp_ipp_state_free(bp_ipp_state* st) {
     if (!st) return BP_OK;
-    (void)hipSetDevice(st->ctx->device);
-    (void)hipStreamSynchronize(st->ctx->stream);
+    (void)hipSetDevice(st->device);
     for (void* p : {st->G, st->H, st->a, st->b, st->gf, st->hf, st->Q, st->pts_tmp, st->sc_tmp, st->cLR, st->partial, st->Pall, st->cG, st->cH, st->sL,
                     st->sR}) if (p) (void)hipFree(p);
     delete st;
@@ -477,7 +477,7 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     bp_ipp_state* st = new (std::nothrow) bp_ipp_state();
     if (!st) return BP_ERR_DEVICE;
     memset(st, 0, sizeof *st);
-    st->ctx = ctx; st->n0 = st->n = n; st->first = true;
+    st->ctx = ctx; st->n0 = st->n = n; st->first = true; st->device = ctx->device;
     st->fold_generators = ctx->ipp_fold_generators;
     hipStream_t s = ctx->stream;
     bool ok = hipMalloc(&st->a, n * 32) == hipSuccess && hipMalloc(&st->b, n * 32) == hipSuccess && hipMalloc(&st->cLR, 64) == hipSuccess &&

@@ -50,17 +50,21 @@ struct bp_ctx {
     int last_ms_n = 0;
 };
 
+// Handles remember their device ordinal so that they can be freed after their context is gone
+// (hipFree synchronises with outstanding work on the device by itself).
 struct bp_g1vec {
     bp_ctx* ctx;
     void* d;
     size_t n;
     bool owned;
+    int device;
 };
 struct bp_frvec {
     bp_ctx* ctx;
     void* d;
     size_t n;
     bool owned;
+    int device;
 };
 
 static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
