@@ -148,7 +148,8 @@ def main():
         if args.curve == "bls12_381" and args.lg_n == 20 and os.path.exists(pmc):
             # HBM bytes per k_accumulate launch from the committed rocprofv3 --pmc passes of this same command
             # (FETCH_SIZE / WRITE_SIZE in KiB; read side doubled per MI355X_MICROARCH.md, uncalibrated for gathers)
-            k = json.load(open(pmc))["kernels"].get("bp::k_accumulate<bp::Bls381>", {})
+            ks = json.load(open(pmc))["kernels"]
+            k = next((v for name, v in ks.items() if name.startswith("bp::k_accumulate<bp::Bls381")), {})
             if "FETCH_SIZE_KiB_avg" in k and "WRITE_SIZE_KiB_avg" in k:
                 traffic = int((2 * k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
                 traffic_note = "profiles/r01_bench_n1_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
