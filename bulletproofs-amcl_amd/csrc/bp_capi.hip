@@ -188,7 +188,7 @@ struct Impl {
         if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));
         {
             dim3 agrid((unsigned)((max_tasks + kBlock - 1) / kBlock));
-            static const int wps = getenv("BP_ACC_WPS") ? atoi(getenv("BP_ACC_WPS")) : 3;
+            static const int wps = getenv("BP_ACC_WPS") ? atoi(getenv("BP_ACC_WPS")) : 2;
             if (wps == 2) hipLaunchKernelGGL((k_accumulate<C, 2>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
             else if (wps == 4) hipLaunchKernelGGL((k_accumulate<C, 4>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
             else hipLaunchKernelGGL((k_accumulate<C, 3>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);

@@ -215,3 +215,86 @@ template <class C> BP_HD Xyzz<C> xyzz_mul_words(const uint32_t (&k)[8], const Af
 }
 
 }  // namespace bp
+
+namespace bp {
+
+// ----------------------------------------------------------------------------------------------- lazy accumulator
+// The bucket-accumulate loop (k_accumulate) keeps its XYZZ accumulator in the bounded domain of bp_field.cuh:
+//     X < 8p,  Y < 4p,  ZZ < 2p,  ZZZ < 2p        (limbs normalised)
+// and adds canonical affine points with madd-2008-s, every intermediate bound tracked in the types:
+//     U2 = x2 ZZ            (1*2)         < 2p          S2 = y2 ZZZ          (1*2)        < 2p
+//     P  = U2 - X + 8p                    < 10p         R  = S2 - Y + 4p                  < 6p
+//     PP = P^2              (10*10)       < 2p          PPP = P PP           (10*2)       < 2p
+//     Q  = X PP             (8*2)         < 2p
+//     X3 = R^2 - PPP - Q - Q  (+2p each)  < 8p          (R^2: 6*6)
+//     Y3 = R (Q - X3 + 8p) - Y PPP + 2p   < 4p          (6*10, 4*2)
+//     ZZ3 = ZZ PP, ZZZ3 = ZZZ PPP         < 2p
+// so the invariant is reproduced and no product exceeds kMaxProd.  Exceptional cases: P == 0 (mod p) is detected with
+// feb_is_zero_mod_p; the (rare) doubling / cancellation / first-point paths go through the strict functions.
+template <class C>
+struct XyzzLazy {
+    using Fp = typename C::Fp;
+    FeB<Fp, 8> x;
+    FeB<Fp, 4> y;
+    FeB<Fp, 2> zz, zzz;
+    bool inf;
+};
+
+template <class C> BP_HD XyzzLazy<C> xyzz_lazy_inf() {
+    using Fp = typename C::Fp;
+    XyzzLazy<C> r;
+    for (int i = 0; i < Fp::NL; i++) { r.x.v[i] = 0; r.y.v[i] = 0; r.zz.v[i] = 0; r.zzz.v[i] = 0; }
+    r.inf = true;
+    return r;
+}
+
+template <class C> BP_HD XyzzLazy<C> xyzz_lazy_from_strict(const Xyzz<C>& p) {
+    using Fp = typename C::Fp;
+    XyzzLazy<C> r;
+    r.x = feb_widen<8>(feb_from_strict<Fp>(p.x));
+    r.y = feb_widen<4>(feb_from_strict<Fp>(p.y));
+    r.zz = feb_widen<2>(feb_from_strict<Fp>(p.zz));
+    r.zzz = feb_widen<2>(feb_from_strict<Fp>(p.zzz));
+    r.inf = xyzz_is_inf(p);
+    return r;
+}
+
+template <class C> BP_HD Xyzz<C> xyzz_lazy_to_strict(const XyzzLazy<C>& p) {
+    if (p.inf) return xyzz_inf<C>();
+    Xyzz<C> r;
+    r.x = feb_to_strict(p.x);
+    r.y = feb_to_strict(p.y);
+    r.zz = feb_to_strict(p.zz);
+    r.zzz = feb_to_strict(p.zzz);
+    return r;
+}
+
+// acc += q  (q canonical affine, possibly the identity)
+template <class C> BP_HD void xyzz_lazy_add_aff(XyzzLazy<C>& a, const Aff<C>& q) {
+    using Fp = typename C::Fp;
+    if (aff_is_inf(q)) return;
+    if (a.inf) { a = xyzz_lazy_from_strict(xyzz_from_aff(q)); return; }
+    FeB<Fp, 1> qx = feb_from_strict<Fp>(q.x), qy = feb_from_strict<Fp>(q.y);
+    FeB<Fp, 2> U2 = feb_mul(qx, a.zz);
+    FeB<Fp, 2> S2 = feb_mul(qy, a.zzz);
+    FeB<Fp, 10> Pp = feb_sub<8>(U2, a.x);
+    FeB<Fp, 6> Rr = feb_sub<4>(S2, a.y);
+    if (feb_is_zero_mod_p(Pp)) {
+        if (feb_is_zero_mod_p(Rr)) a = xyzz_lazy_from_strict(xyzz_dbl_aff(q));     // acc == q
+        else a = xyzz_lazy_inf<C>();                                                // acc == -q
+        return;
+    }
+    FeB<Fp, 2> PP = feb_sqr(Pp);
+    FeB<Fp, 2> PPP = feb_mul(Pp, PP);
+    FeB<Fp, 2> Q = feb_mul(a.x, PP);
+    FeB<Fp, 2> R2 = feb_sqr(Rr);
+    FeB<Fp, 8> X3 = feb_sub<2>(feb_sub<2>(feb_sub<2>(R2, PPP), Q), Q);
+    FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
+    FeB<Fp, 4> Y3 = feb_sub<2>(feb_mul(Rr, QX), feb_mul(a.y, PPP));
+    a.zz = feb_mul(a.zz, PP);
+    a.zzz = feb_mul(a.zzz, PPP);
+    a.x = X3;
+    a.y = Y3;
+}
+
+}  // namespace bp

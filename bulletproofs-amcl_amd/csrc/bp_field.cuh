@@ -324,3 +324,197 @@ template <class P> BP_HD bool words_lt_mod(const uint32_t* a) {
 }
 
 }  // namespace bp
+
+namespace bp {
+
+// =============================================================================================================
+// Lazy ("bounded") arithmetic for hot loops.
+//
+// FeB<P, B> is a field element whose limbs are normalised (< 2^30) and whose VALUE is < B * p; B is part of the
+// type, so every bound below is checked by the compiler.  No conditional subtraction happens anywhere:
+//   mul / sqr : inputs < B1 p, B2 p with B1 * B2 <= kMaxProd  ->  output < 2p
+//               ((x y + m p) / R < p (B1 B2 p / R + 1) and p / R < 2^-7 for every supported field; kMaxProd = 128 keeps
+//               B1 B2 p / R < 1, hence output < 2p.)
+//   add       : limb-wise add + one carry pass                         ->  < (B1 + B2) p
+//   sub<K>    : a - b + K p with K >= B2 (K p precomputed in limbs)     ->  < (B1 + K) p
+// All values stay < 2^(30 NL - 2) (B <= 32), so the top limb never overflows.  Leaving the lazy domain:
+// to_strict() (binary conditional subtraction down to [0, p)).  is_zero_mod_p() tests x == 0 (mod p) for a bounded x.
+// The strict functions above remain the reference semantics; tests compare the two on the golden vectors and on
+// random data through the MSM kernels.
+// =============================================================================================================
+template <class P, int B>
+struct FeB {
+    static_assert(B >= 1 && B <= 32, "bound out of range");
+    uint32_t v[P::NL];
+};
+
+constexpr int kMaxProd = 128;
+
+template <class P>
+struct LazyConsts {
+    // k * p in normalised limbs for k = 1, 2, 4, 8, 16, 32
+    uint32_t kp[6][P::NL];
+    uint32_t pinv;   // p[0]^-1 mod 2^30  (for the multiple-of-p test)
+};
+
+template <class P>
+constexpr LazyConsts<P> make_lazy() {
+    LazyConsts<P> c{};
+    for (int i = 0; i < P::NL; i++) c.kp[0][i] = P::C.mod[i];
+    for (int k = 1; k < 6; k++) {
+        uint32_t carry = 0;
+        for (int i = 0; i < P::NL; i++) { uint32_t x = (c.kp[k - 1][i] << 1) | carry; carry = x >> LB; c.kp[k][i] = x & LMASK; }
+    }
+    uint32_t x = 1;
+    for (int i = 0; i < 6; i++) x *= 2 - P::C.mod[0] * x;
+    c.pinv = x & LMASK;
+    return c;
+}
+template <class P> struct Lazy { static constexpr LazyConsts<P> L = make_lazy<P>(); };
+static_assert(Bls381Fp::NL * LB - Bls381Fp::BITS >= 7 && Bls381Fr::NL * LB - Bls381Fr::BITS >= 7 && Bn254Fp::NL * LB - Bn254Fp::BITS >= 7,
+              "p / R < 2^-7 is assumed by the lazy multiplication bound");
+
+constexpr int log2_ceil_pow2(int k) { return k <= 1 ? 0 : k <= 2 ? 1 : k <= 4 ? 2 : k <= 8 ? 3 : k <= 16 ? 4 : 5; }
+
+template <class P> BP_HD FeB<P, 1> feb_from_strict(const Fe<P>& a) { FeB<P, 1> r; for (int i = 0; i < P::NL; i++) r.v[i] = a.v[i]; return r; }
+// widen the static bound (no-op on the data)
+template <int B2, class P, int B1> BP_HD FeB<P, B2> feb_widen(const FeB<P, B1>& a) {
+    static_assert(B2 >= B1, "cannot narrow a bound");
+    FeB<P, B2> r;
+    for (int i = 0; i < P::NL; i++) r.v[i] = a.v[i];
+    return r;
+}
+
+template <class P, int B1, int B2> BP_HD FeB<P, 2> feb_mul(const FeB<P, B1>& a, const FeB<P, B2>& b) {
+    static_assert(B1 * B2 <= kMaxProd, "operands too large for a lazy Montgomery product");
+    constexpr int N = P::NL;
+    uint32_t t[2 * N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+        t[k] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    t[2 * N - 1] = (uint32_t)acc;
+    uint32_t m[N];
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        acc += t[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
+        acc += (uint64_t)m[k] * P::C.mod[0];
+        acc >>= LB;
+    }
+    FeB<P, 2> r;
+#pragma unroll
+    for (int k = N; k < 2 * N; k++) {
+        acc += t[k];
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        r.v[k - N] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    return r;
+}
+
+template <class P, int B1> BP_HD FeB<P, 2> feb_sqr(const FeB<P, B1>& a) {
+    static_assert(B1 * B1 <= kMaxProd, "operand too large for a lazy Montgomery square");
+    constexpr int N = P::NL;
+    uint32_t a2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) a2[i] = a.v[i] << 1;
+    uint32_t t[2 * N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        t[k] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    t[2 * N - 1] = (uint32_t)acc;
+    uint32_t m[N];
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        acc += t[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
+        acc += (uint64_t)m[k] * P::C.mod[0];
+        acc >>= LB;
+    }
+    FeB<P, 2> r;
+#pragma unroll
+    for (int k = N; k < 2 * N; k++) {
+        acc += t[k];
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        r.v[k - N] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    return r;
+}
+
+template <class P, int B1, int B2> BP_HD FeB<P, B1 + B2> feb_add(const FeB<P, B1>& a, const FeB<P, B2>& b) {
+    FeB<P, B1 + B2> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        uint32_t x = a.v[i] + b.v[i] + c;
+        r.v[i] = x & LMASK;
+        c = x >> LB;
+    }
+    return r;
+}
+
+// a - b + K p,  K a power of two >= B2
+template <int K, class P, int B1, int B2> BP_HD FeB<P, B1 + K> feb_sub(const FeB<P, B1>& a, const FeB<P, B2>& b) {
+    static_assert(K >= B2 && (K & (K - 1)) == 0 && K <= 32, "K p must dominate the subtrahend");
+    constexpr int ki = log2_ceil_pow2(K);
+    FeB<P, B1 + K> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        int32_t x = (int32_t)(a.v[i] + Lazy<P>::L.kp[ki][i]) - (int32_t)b.v[i] + c;   // in (-2^30, 2^31 + 2)
+        r.v[i] = (uint32_t)x & LMASK;
+        c = x >> LB;                                                                   // arithmetic shift: signed carry
+    }
+    return r;
+}
+
+// x < B p  ->  canonical [0, p): conditional subtraction of 2^j p, j descending
+template <class P, int B> BP_HD Fe<P> feb_to_strict(const FeB<P, B>& a) {
+    Fe<P> r;
+    for (int i = 0; i < P::NL; i++) r.v[i] = a.v[i];
+#pragma unroll
+    for (int j = log2_ceil_pow2(B) - 1; j >= 0; j--) {
+        uint32_t d[P::NL];
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < P::NL; i++) {
+            uint32_t x = r.v[i] - Lazy<P>::L.kp[j][i] - br;
+            br = x >> 31;
+            d[i] = x & LMASK;
+        }
+#pragma unroll
+        for (int i = 0; i < P::NL; i++) r.v[i] = br ? r.v[i] : d[i];
+    }
+    return r;
+}
+
+// x == 0 (mod p) for x < B p.  If x = j p then j = x[0] * p[0]^-1 mod 2^30, and j < B: a two-instruction filter that
+// almost never passes for a non-multiple; the full limb comparison runs only when it does.
+template <class P, int B> BP_HD bool feb_is_zero_mod_p(const FeB<P, B>& a) {
+    uint32_t j = (a.v[0] * Lazy<P>::L.pinv) & LMASK;
+    if (j >= (uint32_t)B) return false;
+    Fe<P> s = feb_to_strict<P, B>(a);
+    return fe_is_zero(s);
+}
+
+}  // namespace bp

@@ -346,14 +346,15 @@ __global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* 
     if (j >= *total_tasks) return;
     uint32_t tid = order[j];
     uint32_t s = t_start[tid], e = s + t_len[tid];
-    Xyzz<C> acc = xyzz_inf<C>();
+    // lazy-reduction accumulator (bounded domain, bp_curve.cuh): no conditional subtraction inside the loop
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
     for (; s < e; s++) {
         uint32_t code = idx[s];
         Aff<C> p = aff_unpack(pts[code & 0x7fffffffu]);
         if (code >> 31) p.y = fe_neg(p.y);
-        acc = xyzz_add_aff(acc, p);
+        xyzz_lazy_add_aff(acc, p);
     }
-    tsum[tid] = xyzz_pack(acc);
+    tsum[tid] = xyzz_pack(xyzz_lazy_to_strict(acc));
 }
 
 // ---------------------------------------------------------------------------------------------- bucket reduce
