@@ -102,6 +102,9 @@ SYMBOLS = {
     "bp_vecpoly3_special_inner_product": (_I, [_P, _PP, _PP, _U8P]),
     "bp_vecpoly1_inner_product": (_I, [_P, _PP, _PP, _U8P]),
     "bp_vecpoly_eval": (_I, [_P, _PP, _I, _U8P, _PP]),
+    "bp_r1cs_prover_polys": (_I, [_P, _PP, _U8P, _PP]),
+    "bp_r1cs_ipp_inputs": (_I, [_P, _P, _P, _U8P, _U8P, _SZ, _SZ, _PP]),
+    "bp_r1cs_verifier_scalars": (_I, [_P, _P, _U8P, _U8P, _SZ, _SZ, _SZ, _P, _P, _P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _PP, _PP]),
     "bp_transcript_new": (_I, [_U8P, _SZ, _PP]),
     "bp_transcript_free": (_I, [_P]),
     "bp_transcript_append_message": (_I, [_P, _U8P, _SZ, _U8P, _SZ]),
@@ -578,3 +581,31 @@ class VecPoly3:
         h = ctypes.c_void_p()
         _check(lib().bp_vecpoly_eval(ctx.h, _handles(self.v), 3, bytes(x_le32), ctypes.byref(h)), "bp_vecpoly_eval")
         return FieldElementVector(ctx, h)
+
+
+# ---- R1CS vector pipeline (src/r1cs/prover.rs:458-563, src/r1cs/verifier.rs:342-390) --------------------------------
+
+def r1cs_prover_polys(ctx, a_L, a_R, a_O, s_L, s_R, wL, wR, wO, y_le32):
+    """-> (l_poly, r_poly) as VecPoly3 with the structurally-zero vectors filled by zeros"""
+    out = (ctypes.c_void_p * 6)()
+    _check(lib().bp_r1cs_prover_polys(ctx.h, _handles((a_L, a_R, a_O, s_L, s_R, wL, wR, wO)), bytes(y_le32), out), "bp_r1cs_prover_polys")
+    v = [FieldElementVector(ctx, ctypes.c_void_p(out[i])) for i in range(6)]
+    n = len(a_L)
+    return VecPoly3(FieldElementVector.new(ctx, n), v[0], v[1], v[2]), VecPoly3(v[3], v[4], FieldElementVector.new(ctx, n), v[5])
+
+
+def r1cs_ipp_inputs(ctx, l_eval, r_eval, y_le32, u_le32, n1, padded_n):
+    """-> (l_vec, r_vec, G_factors, H_factors)"""
+    out = (ctypes.c_void_p * 4)()
+    _check(lib().bp_r1cs_ipp_inputs(ctx.h, l_eval.h, r_eval.h, bytes(y_le32), bytes(u_le32), n1, padded_n, out), "bp_r1cs_ipp_inputs")
+    return tuple(FieldElementVector(ctx, ctypes.c_void_p(out[i])) for i in range(4))
+
+
+def r1cs_verifier_scalars(ctx, transcript, L_le, R_le, padded_n, n1, wL, wR, wO, y_inv, x, u, a, b):
+    """-> (u_sq, u_inv_sq, g_scalars, h_scalars)"""
+    lg_n = len(L_le) // ctx.point_bytes
+    us, uis = ctypes.create_string_buffer(max(1, lg_n) * 32), ctypes.create_string_buffer(max(1, lg_n) * 32)
+    g, h = ctypes.c_void_p(), ctypes.c_void_p()
+    _check(lib().bp_r1cs_verifier_scalars(ctx.h, transcript.h, bytes(L_le), bytes(R_le), lg_n, padded_n, n1, wL.h, wR.h, wO.h, bytes(y_inv), bytes(x),
+                                          bytes(u), bytes(a), bytes(b), us, uis, ctypes.byref(g), ctypes.byref(h)), "bp_r1cs_verifier_scalars")
+    return us.raw[: lg_n * 32], uis.raw[: lg_n * 32], FieldElementVector(ctx, g), FieldElementVector(ctx, h)

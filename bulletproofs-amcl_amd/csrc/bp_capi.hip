@@ -16,12 +16,23 @@ struct MsmGeom {
     uint32_t bpw;    // reduce blocks per window (max over windows)
 };
 
-static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1) {
+static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0) {
     int c = c_override;
     if (c <= 0) {
         int lg = 0;
         while (((size_t)1 << (lg + 1)) <= n) lg++;
         c = lg - 1;   // measured (scripts/time_msm.py sweeps): short per-bucket chains beat fewer buckets up to c = 16
+        if (c > 16) c = 16;
+        // ... unless that leaves > 2^17 nearly empty buckets (the bucket reduce costs ~2 ns per bucket whatever they
+        // hold): shrink c until the mean occupancy reaches 8.  nnz = non-zero scalars per set when the caller knows
+        // it (the IPP rounds: half of the generators carry a zero), else n.  (scripts/sweep_ipp_c.py)
+        const size_t live = nnz ? nnz : n;
+        while (c > 8 && nsets > 1) {   // measured for the paired (IPP round) shape only; single-set sweeps favour lg n - 1 throughout
+            uint64_t W1 = (uint64_t)((fr_bits + 1 + c - 1) / c);
+            uint64_t buckets = (uint64_t)nsets * W1 << (c - 1), entries = (uint64_t)nsets * W1 * live;
+            if (buckets <= (1u << 17) || entries >= 8 * buckets) break;
+            c--;
+        }
     }
     if (c < 2) c = 2;
     if (c > 16) c = 16;
@@ -94,8 +105,9 @@ struct Impl {
     }
 
     // Device stage: window sums of  sum_i s_i P_i  into ctx->window_sum (W records).
-    static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g, const ScalarWords* sc2 = nullptr) {
-        msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1);
+    static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g, const ScalarWords* sc2 = nullptr,
+                           size_t nnz = 0) {
+        msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz);
         const WinTab& tab = g.tab;
         const int W = tab.W;
         if (getenv("BP_TRACE")) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d nbuckets=%u m=%u bpw=%u\n", n, g.c, W, tab.nbuckets, g.m, g.bpw);
@@ -253,10 +265,10 @@ struct Impl {
     }
 
     // Two scalar sets over the same points in ONE pipeline pass (2W windows): out1 = <sc1, pts>, out2 = <sc2, pts>.
-    static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le) {
+    static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le, size_t nnz = 0) {
         if (n == 0) { memset(out1_le, 0, 2 * 4 * Fp::NW); memset(out2_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz);
         if (rc) return rc;
         const int W = g.tab.W, W1 = W / 2;
         if ((rc = host_pinned_reserve(ctx, (size_t)W * kXyzzBytes))) return rc;
@@ -337,8 +349,9 @@ int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t
     DISPATCH(ctx, I::msm(ctx, points, 0, scalars, 0, n, out_le));
 }
 
-int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le) {
-    DISPATCH(ctx, I::msm2(ctx, points, scalars1, scalars2, n, out1_le, out2_le));
+int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
+                     size_t nnz) {
+    DISPATCH(ctx, I::msm2(ctx, points, scalars1, scalars2, n, out1_le, out2_le, nnz));
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -599,7 +612,7 @@ int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1
     if (!ctx || !points || !scalars1 || !scalars2 || !out1_le || !out2_le) return BP_ERR_ARG;
     if (points->n != scalars1->n || points->n != scalars2->n) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
-    return bp_internal_msm2(ctx, points->d, scalars1->d, scalars2->d, points->n, out1_le, out2_le);
+    return bp_internal_msm2(ctx, points->d, scalars1->d, scalars2->d, points->n, out1_le, out2_le, 0);
 }
 
 size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {

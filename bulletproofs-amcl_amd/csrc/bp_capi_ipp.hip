@@ -108,7 +108,7 @@ struct Ipp {
                                (const ScalarWords*)st->cH, cLR, st->n0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
-            return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le);   // both sums in one pipeline pass
+            return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1);   // both sums in one pipeline pass
         }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
                            (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,
@@ -268,6 +268,59 @@ struct Ipp {
     } while (0)
 
 int alloc_frvec(bp_ctx* ctx, size_t n, bp_frvec** out) { return bp_frvec_alloc(ctx, n, out); }
+
+template <class C>
+static int r1cs_prover_polys_impl(bp_ctx* ctx, const bp_frvec* const in[8], const uint8_t* y_le32, size_t n, bp_frvec* const outv[6]) {
+    using F = typename C::Fr;
+    Fe<F> y = fr_from_le<F>(y_le32), yi = fe_inv<F>(y);
+    auto I = [&](int k) { return (const ScalarWords*)in[k]->d; };
+    auto O = [&](int k) { return (ScalarWords*)outv[k]->d; };
+    hipLaunchKernelGGL(k_r1cs_prover_polys<C>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7),
+                       fr_mont_words<F>(y), fr_mont_words<F>(yi), n, O(0), O(1), O(2), O(3), O(4), O(5));
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+template <class C>
+static int r1cs_ipp_inputs_impl(bp_ctx* ctx, const bp_frvec* l_eval, const bp_frvec* r_eval, const uint8_t* y_le32, const uint8_t* u_le32, size_t n1,
+                                size_t padded_n, bp_frvec* const outv[4]) {
+    using F = typename C::Fr;
+    Fe<F> y = fr_from_le<F>(y_le32), yi = fe_inv<F>(y), u = fr_from_le<F>(u_le32);
+    hipLaunchKernelGGL(k_r1cs_ipp_inputs<C>, dim3(blocks_for(padded_n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)l_eval->d,
+                       (const ScalarWords*)r_eval->d, fr_mont_words<F>(y), fr_mont_words<F>(yi), fr_mont_words<F>(u), l_eval->n, n1, padded_n,
+                       (ScalarWords*)outv[0]->d, (ScalarWords*)outv[1]->d, (ScalarWords*)outv[2]->d, (ScalarWords*)outv[3]->d);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+template <class C>
+static int r1cs_verifier_scalars_impl(bp_ctx* ctx, Transcript& t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t padded_n, size_t n1,
+                                      const bp_frvec* wL, const bp_frvec* wR, const bp_frvec* wO, const uint8_t* yinv_le, const uint8_t* x_le,
+                                      const uint8_t* u_le, const uint8_t* a_le, const uint8_t* b_le, uint8_t* u_sq, uint8_t* u_inv_sq, bp_frvec* g_sc,
+                                      bp_frvec* h_sc) {
+    using F = typename C::Fr;
+    std::vector<Fe<F>> ch, ch_inv;
+    int rc = Ipp<C>::verification_scalars(t, L_le, R_le, lg_n, padded_n, ch, ch_inv);     // IPP::verification_scalars, verifier.rs:354-360
+    if (rc) return rc;
+    std::vector<ScalarWords> hch(2 * lg_n + 1);
+    for (size_t j = 0; j < lg_n; j++) {
+        hch[j] = fr_mont_words<F>(ch[j]);
+        hch[lg_n + j] = fr_mont_words<F>(ch_inv[j]);
+        fr_to_le<F>(fe_sqr(ch[j]), u_sq + 32 * j);
+        fr_to_le<F>(fe_sqr(ch_inv[j]), u_inv_sq + 32 * j);
+    }
+    if ((rc = ctx->scratch.reserve((2 * lg_n + 1) * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->scratch.p, hch.data(), (2 * lg_n + 1) * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_r1cs_verifier_scalars<C>, dim3(blocks_for(padded_n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)wL->d,
+                       (const ScalarWords*)wR->d, (const ScalarWords*)wO->d, (const ScalarWords*)ctx->scratch.p, (const ScalarWords*)ctx->scratch.p + lg_n,
+                       (int)lg_n, fr_mont_words<F>(fr_from_le<F>(yinv_le)), fr_mont_words<F>(fr_from_le<F>(x_le)), fr_mont_words<F>(fr_from_le<F>(u_le)),
+                       fr_mont_words<F>(fr_from_le<F>(a_le)), fr_mont_words<F>(fr_from_le<F>(b_le)), wL->n, n1, padded_n, (ScalarWords*)g_sc->d,
+                       (ScalarWords*)h_sc->d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // hch is a host temporary
+    return BP_OK;
+}
+
 
 }  // namespace
 
@@ -453,6 +506,61 @@ int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uin
                            fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(x_le32)), n, (ScalarWords*)(*out)->d);
     HIPCHK(hipGetLastError());
     return BP_OK;
+}
+
+// ---- R1CS vector pipeline (src/r1cs/prover.rs:458-563, src/r1cs/verifier.rs:342-390) ------------------------
+
+int bp_r1cs_prover_polys(bp_ctx* ctx, const bp_frvec* const in[8], const uint8_t* y_le32, bp_frvec* out[6]) {
+    if (!ctx || !in || !y_le32 || !out) return BP_ERR_ARG;
+    size_t n;
+    int rc;
+    if ((rc = same_len(in, 8, &n))) return rc;
+    if ((rc = bp_internal_set_device(ctx))) return rc;
+    for (int k = 0; k < 6; k++) out[k] = nullptr;
+    for (int k = 0; k < 6; k++) if ((rc = alloc_frvec(ctx, n, &out[k]))) { for (int j = 0; j < k; j++) bp_frvec_free(out[j]); return rc; }
+    if (n == 0) return BP_OK;
+    rc = ctx->curve == BP_CURVE_BLS12_381 ? r1cs_prover_polys_impl<Bls381>(ctx, in, y_le32, n, out) : r1cs_prover_polys_impl<Bn254>(ctx, in, y_le32, n, out);
+    if (rc) for (int k = 0; k < 6; k++) { bp_frvec_free(out[k]); out[k] = nullptr; }
+    return rc;
+}
+
+
+int bp_r1cs_ipp_inputs(bp_ctx* ctx, const bp_frvec* l_eval, const bp_frvec* r_eval, const uint8_t* y_le32, const uint8_t* u_le32, size_t n1,
+                       size_t padded_n, bp_frvec* out[4]) {
+    if (!ctx || !l_eval || !r_eval || !y_le32 || !u_le32 || !out) return BP_ERR_ARG;
+    if (l_eval->n != r_eval->n) return BP_ERR_LENGTH;
+    if (padded_n < l_eval->n || n1 > l_eval->n || padded_n == 0 || (padded_n & (padded_n - 1))) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    for (int k = 0; k < 4; k++) out[k] = nullptr;
+    for (int k = 0; k < 4; k++) if ((rc = alloc_frvec(ctx, padded_n, &out[k]))) { for (int j = 0; j < k; j++) bp_frvec_free(out[j]); return rc; }
+    rc = ctx->curve == BP_CURVE_BLS12_381 ? r1cs_ipp_inputs_impl<Bls381>(ctx, l_eval, r_eval, y_le32, u_le32, n1, padded_n, out)
+                                          : r1cs_ipp_inputs_impl<Bn254>(ctx, l_eval, r_eval, y_le32, u_le32, n1, padded_n, out);
+    if (rc) for (int k = 0; k < 4; k++) { bp_frvec_free(out[k]); out[k] = nullptr; }
+    return rc;
+}
+
+
+int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t padded_n, size_t n1,
+                             const bp_frvec* wL, const bp_frvec* wR, const bp_frvec* wO, const uint8_t* y_inv_le32, const uint8_t* x_le32,
+                             const uint8_t* u_le32, const uint8_t* a_le32, const uint8_t* b_le32, uint8_t* u_sq_out, uint8_t* u_inv_sq_out,
+                             bp_frvec** g_scalars, bp_frvec** h_scalars) {
+    if (!ctx || !t || !wL || !wR || !wO || !y_inv_le32 || !x_le32 || !u_le32 || !a_le32 || !b_le32 || !u_sq_out || !u_inv_sq_out || !g_scalars ||
+        !h_scalars || (lg_n && (!L_le || !R_le)))
+        return BP_ERR_ARG;
+    if (wL->n != wR->n || wL->n != wO->n) return BP_ERR_LENGTH;
+    if (lg_n >= 32 || padded_n != ((size_t)1 << lg_n)) return BP_ERR_VERIFY;
+    if (wL->n > padded_n || n1 > wL->n) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    *g_scalars = *h_scalars = nullptr;
+    if ((rc = alloc_frvec(ctx, padded_n, g_scalars))) return rc;
+    if ((rc = alloc_frvec(ctx, padded_n, h_scalars))) { bp_frvec_free(*g_scalars); *g_scalars = nullptr; return rc; }
+    rc = ctx->curve == BP_CURVE_BLS12_381
+             ? r1cs_verifier_scalars_impl<Bls381>(ctx, t->t, L_le, R_le, lg_n, padded_n, n1, wL, wR, wO, y_inv_le32, x_le32, u_le32, a_le32, b_le32,
+                                                  u_sq_out, u_inv_sq_out, *g_scalars, *h_scalars)
+             : r1cs_verifier_scalars_impl<Bn254>(ctx, t->t, L_le, R_le, lg_n, padded_n, n1, wL, wR, wO, y_inv_le32, x_le32, u_le32, a_le32, b_le32,
+                                                 u_sq_out, u_inv_sq_out, *g_scalars, *h_scalars);
+    if (rc) { bp_frvec_free(*g_scalars); bp_frvec_free(*h_scalars); *g_scalars = *h_scalars = nullptr; }
+    return rc;
 }
 
 // ---- IPP device-resident state ------------------------------------------------------------------------------

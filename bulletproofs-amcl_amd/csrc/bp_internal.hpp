@@ -92,5 +92,7 @@ static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
 
 // MSM over raw resident device arrays (n > 0 or n == 0 -> identity); defined in bp_capi.hip.
 int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le);
-int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le);
+// nnz = non-zero scalars per set if known (0: assume n)
+int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
+                     size_t nnz);
 int bp_internal_set_device(const bp_ctx* ctx);

@@ -187,6 +187,95 @@ __global__ void __launch_bounds__(kBlock) k_vecpoly_eval(const ScalarWords* __re
     fr_store<F>(out, i, acc);
 }
 
+// ---------------------------------------------------------------------------------------------- R1CS vector pipeline
+// (the Fr work either side of the IPP in the R1CS prover and verifier.)
+template <class F>
+__device__ __forceinline__ Fe<F> fr_pow_index(const Fe<F>& base_mont, size_t e) {   // base^e, Montgomery in/out
+    Fe<F> acc = fe_one<F>(), b = base_mont;
+    for (size_t k = e; k; k >>= 1) {
+        if (k & 1) acc = fe_mul(acc, b);
+        b = fe_sqr(b);
+    }
+    return acc;
+}
+
+// Prover: l(X), r(X) coefficient vectors, /root/reference src/r1cs/prover.rs:465-486
+//   l1 = a_L + y^-i wR     l2 = a_O     l3 = s_L        r0 = wO - y^i     r1 = y^i a_R + wL     r3 = y^i s_R
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_r1cs_prover_polys(const ScalarWords* __restrict__ aL, const ScalarWords* __restrict__ aR,
+                                                              const ScalarWords* __restrict__ aO, const ScalarWords* __restrict__ sL,
+                                                              const ScalarWords* __restrict__ sR, const ScalarWords* __restrict__ wL,
+                                                              const ScalarWords* __restrict__ wR, const ScalarWords* __restrict__ wO,
+                                                              ScalarWords y_mont, ScalarWords yinv_mont, size_t n, ScalarWords* __restrict__ l1,
+                                                              ScalarWords* __restrict__ l2, ScalarWords* __restrict__ l3, ScalarWords* __restrict__ r0,
+                                                              ScalarWords* __restrict__ r1, ScalarWords* __restrict__ r3) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> yi = fr_pow_index<F>(fe_unpack_words<F>(y_mont.w), i), yni = fr_pow_index<F>(fe_unpack_words<F>(yinv_mont.w), i);   // Montgomery
+    fr_store<F>(l1, i, fe_add(fr_load<F>(aL, i), fe_mul(fr_load<F>(wR, i), yni)));
+    l2[i] = aO[i];
+    l3[i] = sL[i];
+    fr_store<F>(r0, i, fe_sub(fr_load<F>(wO, i), fe_from_mont<F>(yi)));
+    fr_store<F>(r1, i, fe_add(fe_mul(fr_load<F>(aR, i), yi), fr_load<F>(wL, i)));
+    fr_store<F>(r3, i, fe_mul(fr_load<F>(sR, i), yi));
+}
+
+// Prover: inputs of create_ipp, src/r1cs/prover.rs:526-563
+//   l_vec = l(x) | 0...   r_vec = r(x) | -y^i (i >= n)   G_factors = 1 (i < n1) | u   H_factors = y^-i * G_factors
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_r1cs_ipp_inputs(const ScalarWords* __restrict__ l_eval, const ScalarWords* __restrict__ r_eval,
+                                                            ScalarWords y_mont, ScalarWords yinv_mont, ScalarWords u_mont, size_t n, size_t n1,
+                                                            size_t padded_n, ScalarWords* __restrict__ l_vec, ScalarWords* __restrict__ r_vec,
+                                                            ScalarWords* __restrict__ gf, ScalarWords* __restrict__ hf) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= padded_n) return;
+    Fe<F> u_or_1 = i < n1 ? fe_one<F>() : fe_unpack_words<F>(u_mont.w);
+    fr_store<F>(gf, i, fe_from_mont<F>(u_or_1));
+    fr_store<F>(hf, i, fe_from_mont<F>(fe_mul(fr_pow_index<F>(fe_unpack_words<F>(yinv_mont.w), i), u_or_1)));
+    if (i < n) {
+        l_vec[i] = l_eval[i];
+        r_vec[i] = r_eval[i];
+    } else {
+        fr_store<F>(l_vec, i, fe_zero<F>());
+        fr_store<F>(r_vec, i, fe_from_mont<F>(fe_neg(fr_pow_index<F>(fe_unpack_words<F>(y_mont.w), i))));
+    }
+}
+
+// Verifier: scalars of G and H in the single verification MSM, src/r1cs/verifier.rs:342-390
+//   g_i = u_or_1 (x y^-i wR_i - a s_i)        h_i = u_or_1 (y^-i (x wL_i + wO_i - b / s_i) - 1)
+// with wL/wR/wO = 0 for i >= n, s_i as in k_ipp_verify_terms (1/s_i = s_(padded_n-1-i)).
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_r1cs_verifier_scalars(const ScalarWords* __restrict__ wL, const ScalarWords* __restrict__ wR,
+                                                                  const ScalarWords* __restrict__ wO, const ScalarWords* __restrict__ ch,
+                                                                  const ScalarWords* __restrict__ ch_inv, int lg_n, ScalarWords yinv_mont,
+                                                                  ScalarWords x_mont, ScalarWords u_mont, ScalarWords a_mont, ScalarWords b_mont,
+                                                                  size_t n, size_t n1, size_t padded_n, ScalarWords* __restrict__ g_sc,
+                                                                  ScalarWords* __restrict__ h_sc) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= padded_n) return;
+    Fe<F> s = fe_one<F>(), sinv = fe_one<F>();
+    for (int j = 0; j < lg_n; j++) {
+        bool bit = (i >> (lg_n - 1 - j)) & 1;
+        Fe<F> uj = fr_load<F>(ch, j), ujinv = fr_load<F>(ch_inv, j);
+        s = fe_mul(s, bit ? uj : ujinv);
+        sinv = fe_mul(sinv, bit ? ujinv : uj);
+    }
+    Fe<F> x = fe_unpack_words<F>(x_mont.w), a = fe_unpack_words<F>(a_mont.w), b = fe_unpack_words<F>(b_mont.w);
+    Fe<F> u_or_1 = i < n1 ? fe_one<F>() : fe_unpack_words<F>(u_mont.w);
+    Fe<F> yni = fr_pow_index<F>(fe_unpack_words<F>(yinv_mont.w), i);
+    Fe<F> zero = fe_zero<F>();
+    // everything below in Montgomery form; canonical vector entries are lifted with fe_to_mont
+    Fe<F> wl = i < n ? fe_to_mont<F>(fr_load<F>(wL, i)) : zero, wr = i < n ? fe_to_mont<F>(fr_load<F>(wR, i)) : zero,
+          wo = i < n ? fe_to_mont<F>(fr_load<F>(wO, i)) : zero;
+    Fe<F> g = fe_mul(u_or_1, fe_sub(fe_mul(x, fe_mul(yni, wr)), fe_mul(a, s)));
+    Fe<F> h = fe_mul(u_or_1, fe_sub(fe_mul(yni, fe_sub(fe_add(fe_mul(x, wl), wo), fe_mul(b, sinv))), fe_one<F>()));
+    fr_store<F>(g_sc, i, fe_from_mont<F>(g));
+    fr_store<F>(h_sc, i, fe_from_mont<F>(h));
+}
+
 // ---------------------------------------------------------------------------------------------- IPP round
 // Assemble the MSM terms of L and R for the current round of length n = 2h (src/ipp.rs:80-104 / :148-170):
 //   L: points [G_R | H_L | Q], scalars [a_L (.Gf_R) | b_R (.Hf_L) | c_L]

@@ -212,6 +212,24 @@ int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_fac
 int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, uint8_t* u_sq,
                                 uint8_t* u_inv_sq, uint8_t* s);
 
+/* ---- R1CS vector pipeline either side of the IPP ---------------------------------------------- */
+/* Prover, src/r1cs/prover.rs:465-486.  in = {a_L, a_R, a_O, s_L, s_R, wL, wR, wO} (equal lengths n; wL.. are the
+ * flattened constraints, computed on the host); out = {l1, l2, l3, r0, r1, r3}: the non-zero coefficient vectors of
+ * l(X) = l1 X + l2 X^2 + l3 X^3 and r(X) = r0 + r1 X + r3 X^3 (feed bp_vecpoly3_special_inner_product / bp_vecpoly_eval). */
+int bp_r1cs_prover_polys(bp_ctx* ctx, const bp_frvec* const in[8], const uint8_t* y_le32, bp_frvec* out[6]);
+/* Prover, src/r1cs/prover.rs:526-563.  out = {l_vec, r_vec, G_factors, H_factors}, all of length padded_n:
+ * l_vec = l(x) | 0,  r_vec = r(x) | -y^i,  G_factors = 1 (i < n1) | u,  H_factors = y^-i * G_factors. */
+int bp_r1cs_ipp_inputs(bp_ctx* ctx, const bp_frvec* l_eval, const bp_frvec* r_eval, const uint8_t* y_le32, const uint8_t* u_le32, size_t n1,
+                       size_t padded_n, bp_frvec* out[4]);
+/* Verifier, src/r1cs/verifier.rs:342-390.  Replays IPP::verification_scalars on the transcript (L, R of the proof),
+ * writes u_j^2 / u_j^-2 (lg_n x 32 B each) and returns the G and H scalars of the single verification MSM:
+ * g_i = u_or_1 (x y^-i wR_i - a s_i),  h_i = u_or_1 (y^-i (x wL_i + wO_i - b s_(N-1-i)) - 1),  wL/wR/wO (length n) = 0
+ * beyond n.  BP_ERR_VERIFY if lg_n >= 32 or padded_n != 2^lg_n. */
+int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t padded_n, size_t n1,
+                             const bp_frvec* wL, const bp_frvec* wR, const bp_frvec* wO, const uint8_t* y_inv_le32, const uint8_t* x_le32,
+                             const uint8_t* u_le32, const uint8_t* a_le32, const uint8_t* b_le32, uint8_t* u_sq_out, uint8_t* u_inv_sq_out,
+                             bp_frvec** g_scalars, bp_frvec** h_scalars);
+
 #ifdef __cplusplus
 }
 #endif

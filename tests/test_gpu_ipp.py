@@ -85,6 +85,53 @@ def test_vector_poly_kernels(bp, ctxs, name):
         bp.VecPoly1(dev[0], bp.FieldElementVector.from_ints(ctx, [1, 2])).eval(xb)
 
 
+@pytest.mark.parametrize("name", CURVES)
+def test_r1cs_vector_pipeline(bp, ctxs, name):
+    """src/r1cs/prover.rs:465-563 and src/r1cs/verifier.rs:342-390 restated with Python ints."""
+    ctx = ctxs[name]
+    cid, r = ctx.curve, ctx.r
+    n, n1, padded_n, lg = 11, 7, 16, 4
+    iv = lambda seed, k=n: ints(O.random_scalars(cid, seed, k))
+    aL, aR, aO, sL, sR, wL, wR, wO = (iv(1300 + j) for j in range(8))
+    y, x, u, a, b = iv(1400, 5)
+    yb, xb, ub, ab, bb = (v.to_bytes(32, "little") for v in (y, x, u, a, b))
+    dev = lambda v: bp.FieldElementVector.from_ints(ctx, v)
+    d = [dev(v) for v in (aL, aR, aO, sL, sR, wL, wR, wO)]
+    yi = pow(y, -1, r)
+    lp, rp = bp.r1cs_prover_polys(ctx, *d, yb)
+    got = [ints(v.to_bytes()) for v in (lp.v[1], lp.v[2], lp.v[3], rp.v[0], rp.v[1], rp.v[3])]
+    want = [[(aL[i] + pow(yi, i, r) * wR[i]) % r for i in range(n)], aO, sL, [(wO[i] - pow(y, i, r)) % r for i in range(n)],
+            [(pow(y, i, r) * aR[i] + wL[i]) % r for i in range(n)], [pow(y, i, r) * sR[i] % r for i in range(n)]]
+    assert got == want
+    assert ints(lp.v[0].to_bytes()) == [0] * n and ints(rp.v[2].to_bytes()) == [0] * n
+    # t(x) coefficients and evaluations through the vector-poly kernels
+    l_eval, r_eval = lp.eval(xb), rp.eval(xb)
+    lx = [(x * (want[0][i] + x * (want[1][i] + x * want[2][i]))) % r for i in range(n)]
+    rx = [(want[3][i] + x * (want[4][i] + x * x * want[5][i])) % r for i in range(n)]
+    assert ints(l_eval.to_bytes()) == lx and ints(r_eval.to_bytes()) == rx
+    lv, rv, gf, hf = bp.r1cs_ipp_inputs(ctx, l_eval, r_eval, yb, ub, n1, padded_n)
+    assert ints(lv.to_bytes()) == lx + [0] * (padded_n - n)
+    assert ints(rv.to_bytes()) == rx + [(-pow(y, i, r)) % r for i in range(n, padded_n)]
+    gfw = [1] * n1 + [u] * (padded_n - n1)
+    assert ints(gf.to_bytes()) == gfw
+    assert ints(hf.to_bytes()) == [pow(yi, i, r) * gfw[i] % r for i in range(padded_n)]
+    # verifier scalars: any lg points serve as L, R for the transcript replay
+    gen = O.generator(cid)
+    L = b"".join(O.g1_mul(cid, (3 + j).to_bytes(32, "little"), gen) for j in range(lg))
+    R = b"".join(O.g1_mul(cid, (30 + j).to_bytes(32, "little"), gen) for j in range(lg))
+    us, uis, gs, hs = bp.r1cs_verifier_scalars(ctx, bp.Transcript(b"R1CSTest"), L, R, padded_n, n1, d[5], d[6], d[7], yi.to_bytes(32, "little"), xb, ub, ab, bb)
+    rc, (us_w, uis_w, s_w) = O.ipp_verification_scalars(cid, O.Transcript(b"R1CSTest"), L, R, lg, padded_n)
+    assert rc == 0 and us == us_w and uis == uis_w
+    s = ints(s_w)
+    pad0 = lambda v: v + [0] * (padded_n - n)
+    wLp, wRp, wOp = pad0(wL), pad0(wR), pad0(wO)
+    g_w = [gfw[i] * (x * pow(yi, i, r) * wRp[i] - a * s[i]) % r for i in range(padded_n)]
+    h_w = [gfw[i] * (pow(yi, i, r) * (x * wLp[i] + wOp[i] - b * s[padded_n - 1 - i]) - 1) % r for i in range(padded_n)]
+    assert ints(gs.to_bytes()) == g_w and ints(hs.to_bytes()) == h_w
+    with pytest.raises(bp.VerificationError):
+        bp.r1cs_verifier_scalars(ctx, bp.Transcript(b"R1CSTest"), L, R, 2 * padded_n, n1, d[5], d[6], d[7], yb, xb, ub, ab, bb)
+
+
 def load_case(bp, ctx, c):
     n = c["n"]
     cat = lambda k: b"".join(hx(x) for x in c[k])
