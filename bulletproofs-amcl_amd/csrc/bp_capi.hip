@@ -116,10 +116,17 @@ struct Impl {
         hipStream_t st = ctx->stream;
         size_t nb = tab.nbuckets;
         size_t scan_blocks = (nb + kScanPerBlock - 1) / kScanPerBlock;
-        // task length: power of two >= 128 and >= 2x the mean bucket size
-        uint32_t L = 128, lshift = 0;
-        while ((uint64_t)L * nb < 2 * (uint64_t)W * n && L < (1u << 20)) { L <<= 1; lshift++; }
+        // task length (see bp_kernels.cuh): >= 2x the mean bucket size when buckets are plentiful, else small enough
+        // for ~kTaskTarget tasks (a few times the 131072 resident lanes of k_accumulate)
+        static const uint64_t kTaskTarget = getenv("BP_TASK_TARGET") ? (uint64_t)atoll(getenv("BP_TASK_TARGET")) : 2 * 131072;
+        const uint64_t entries = (uint64_t)W * (nnz ? nnz : n);
+        uint32_t L = 8;
+        if (nb >= kTaskTarget) { while ((uint64_t)L * nb < 2 * entries && L < (1u << 20)) L <<= 1; if (L < 128) L = 128; }
+        else { while ((uint64_t)L * kTaskTarget < entries && L < (1u << 20)) L <<= 1; }
+        uint32_t lshift = 0;
+        while ((128u << lshift) < L) lshift++;
         size_t max_split = ((size_t)W * n) / L + 1;                         // tasks beyond one per bucket
+        if (max_split > (size_t)W * n) max_split = (size_t)W * n;
         size_t max_tasks = nb + max_split;
         size_t max_heavy = (nb < max_split ? nb : max_split) + 1;
         int rc;
@@ -206,6 +213,7 @@ struct Impl {
             else hipLaunchKernelGGL((k_accumulate<C, 3>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
         }
         if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
+        hipLaunchKernelGGL(k_combine_light<C>, dim3(bgrid), dim3(kBlock), 0, st, task_off, ntasks, (uint32_t)nb, tsum);
         hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)max_heavy), dim3(64), 0, st, heavy, nheavy, task_off, ntasks, tsum);
         BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
         hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(g.bpw, W), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);

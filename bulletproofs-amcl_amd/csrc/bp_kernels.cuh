@@ -256,10 +256,13 @@ static __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in
 // points into one bucket).  Tasks are then ordered by length, longest first (counting sort), so that the 64
 // lanes of a wave run the same number of additions: with Poisson(32) bucket sizes an unsorted wave waits for
 // its longest lane, ~1.45x the mean.
-// The task length L is a power of two >= 128 chosen per call (>= 2x the mean bucket size, so that with uniformly
-// random scalars every bucket is a single task); lengths are binned into 129 classes, longest first.
+// The task length L is a power of two chosen per call: when there are plenty of buckets (>> resident lanes) it is
+// >= 2x the mean bucket size, so that with uniformly random scalars every bucket is one task; when buckets are few it
+// is smaller, so that there are several times more tasks than lanes (otherwise the last, partly filled round of
+// waves costs up to half of the kernel).  Lengths are binned into <= 129 classes, longest first.
 constexpr uint32_t kTaskBins = 129;
-__device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = log2(L) - 7
+constexpr uint32_t kLightMax = 8;   // buckets of 2..kLightMax tasks are summed by one lane (k_combine_light), more by a wave
+__device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = max(0, log2(L) - 7)
 
 // thread per bucket: ntasks[g], and a histogram of task lengths
 static __global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
@@ -289,8 +292,9 @@ static __global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __re
     if (threadIdx.x == 0) *total = tot;
 }
 
-// thread per bucket: emit its tasks.  task id = task_off[g] + k; order[] lists task ids longest first.
-// t_start/t_len describe the slot range of a task.  Buckets with more than one task are appended to heavy[].
+// thread per bucket: emit its tasks.  task id = task_off[g] + k; order[] lists task ids longest first (positions are
+// reserved per block through LDS histograms: one global atomic per (block, length class)).  t_start/t_len describe the
+// slot range of a task.  Buckets with more than kLightMax tasks are appended to heavy[].
 static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
                                                        uint32_t L, uint32_t lshift, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ bin_cursor,
                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ t_start, uint32_t* __restrict__ t_len,
@@ -299,38 +303,31 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
     __syncthreads();
     uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t size = 0, s0 = 0, toff = 0, rank = 0, bin = 0;
-    bool single = false;
+    uint32_t size = 0, s0 = 0, toff = 0, nfull = 0, rem = 0, rank_full = 0, rank_rem = 0, bin_rem = 0;
     if (g < nbuckets) {
         s0 = start[g];
         size = end[g] - s0;
         toff = task_off[g];
-        if (size > 0 && size <= L) {                  // the common case: one task, ranked inside the block
-            single = true;
-            bin = task_bin(size, L, lshift);
-            rank = atomicAdd(&lh[bin], 1u);
-        }
+        nfull = size / L;                              // tasks of exactly L points (bin 0), ranked inside the block
+        rem = size % L;                                // plus one shorter task
+        if (nfull) rank_full = atomicAdd(&lh[0], nfull);
+        if (rem) { bin_rem = task_bin(rem, L, lshift); rank_rem = atomicAdd(&lh[bin_rem], 1u); }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lbase[b] = lh[b] ? atomicAdd(&bin_cursor[b], lh[b]) : 0;
     __syncthreads();
-    if (single) {
-        order[lbase[bin] + rank] = toff;
-        t_start[toff] = s0;
-        t_len[toff] = size;
-    } else if (size > L) {                           // rare: a heavy bucket emits its tasks with global atomics
-        uint32_t nt = (size + L - 1) / L;
-        uint32_t nfull = size / L;
-        uint32_t pos0 = nfull ? atomicAdd(&bin_cursor[0], nfull) : 0;   // all full-length tasks in one reservation
-        for (uint32_t k = 0; k < nt; k++) {
-            uint32_t len = size - k * L < L ? size - k * L : L;
-            uint32_t pos = k < nfull ? pos0 + k : atomicAdd(&bin_cursor[task_bin(len, L, lshift)], 1u);
-            order[pos] = toff + k;
-            t_start[toff + k] = s0 + k * L;
-            t_len[toff + k] = len;
-        }
-        heavy[atomicAdd(nheavy, 1u)] = g;
+    if (size == 0) return;
+    for (uint32_t k = 0; k < nfull; k++) {
+        order[lbase[0] + rank_full + k] = toff + k;
+        t_start[toff + k] = s0 + k * L;
+        t_len[toff + k] = L;
     }
+    if (rem) {
+        order[lbase[bin_rem] + rank_rem] = toff + nfull;
+        t_start[toff + nfull] = s0 + nfull * L;
+        t_len[toff + nfull] = rem;
+    }
+    if (nfull + (rem ? 1u : 0u) > kLightMax) heavy[atomicAdd(nheavy, 1u)] = g;
 }
 
 // ---------------------------------------------------------------------------------------------- bucket accumulate
@@ -375,6 +372,20 @@ __device__ __forceinline__ Xyzz<C> block_tree_sum(Xyzz<C> mine, XyzzPacked<C>* l
         __syncthreads();
     }
     return mine;
+}
+
+// Lane per bucket: buckets cut into 2..kLightMax tasks are summed sequentially -> tsum[task_off[g]].
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_combine_light(const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks, uint32_t nbuckets,
+                                                          XyzzPacked<C>* __restrict__ tsum) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nbuckets) return;
+    uint32_t nt = ntasks[g];
+    if (nt < 2 || nt > kLightMax) return;
+    uint32_t t0 = task_off[g];
+    Xyzz<C> acc = xyzz_unpack(tsum[t0]);
+    for (uint32_t k = 1; k < nt; k++) acc = xyzz_add(acc, xyzz_unpack(tsum[t0 + k]));
+    tsum[t0] = xyzz_pack(acc);
 }
 
 // One wave per heavy bucket (grid = an upper bound; surplus waves exit): sum of its tasks -> tsum[task_off[g]].
