@@ -99,6 +99,7 @@ def main():
             return pts.multi_scalar_mul_var_time(sv)
         bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
         allrec = sharding.all_gather_records(mine, world)          # RCCL all_gather_into_tensor
+        torch.cuda.current_stream(dev).synchronize()               # the gather must be complete before the D2H of finish
         return bp.msm_finish(ctx, allrec.data_ptr(), world, n)
 
     def fence():
@@ -123,11 +124,10 @@ def main():
     ctx.enable_timing(True)
     acc_ms, dev_ms = [], []
     for _ in range(max(3, min(args.steps, 10))):
-        if world == 1:
+        if not use_dist:
             pts.multi_scalar_mul_var_time(sv)
         else:
             bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
-            bp.msm_finish(ctx, mine.data_ptr(), 1, n)
         tm = ctx.last_timing()
         if len(tm) >= 7:
             dev_ms.append(tm[0])

@@ -69,6 +69,7 @@ SYMBOLS = {
     "bp_ctx_set_stream": (_I, [_P, _P]),
     "bp_ctx_synchronize": (_I, [_P]),
     "bp_ctx_set_window_bits": (_I, [_P, _I]),
+    "bp_ctx_set_device_tail": (_I, [_P, _I]),
     "bp_ctx_enable_timing": (_I, [_P, _I]),
     "bp_g1vec_upload": (_I, [_P, _U8P, _SZ, _I, _PP]),
     "bp_g1vec_alloc": (_I, [_P, _SZ, _PP]),
@@ -198,6 +199,9 @@ class Context:
 
     def synchronize(self):
         _check(lib().bp_ctx_synchronize(self.h), "bp_ctx_synchronize")
+
+    def set_device_tail(self, on):
+        _check(lib().bp_ctx_set_device_tail(self.h, 1 if on else 0), "bp_ctx_set_device_tail")
 
     def set_window_bits(self, c):
         _check(lib().bp_ctx_set_window_bits(self.h, c), "bp_ctx_set_window_bits")

@@ -265,6 +265,16 @@ struct Impl {
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
+        if (ctx->device_tail) {   // all-device variant: one lane folds the windows (see k_tail_fold)
+            if ((rc = ctx->scratch.reserve(2 * 4 * Fp::NW))) return rc;
+            hipLaunchKernelGGL(k_tail_fold<C>, dim3(1), dim3(64), 0, ctx->stream, (const XyzzPacked<C>*)ctx->window_sum.p, g.tab, 0, g.tab.W,
+                               (uint32_t*)ctx->scratch.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(out_le, ctx->scratch.p, 2 * 4 * Fp::NW, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            collect_timing(ctx);
+            return BP_OK;
+        }
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
@@ -293,6 +303,9 @@ struct Impl {
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(device_out, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToDevice, ctx->stream));
+        // The records are about to be read by another stream (RCCL's): complete them before returning.
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        collect_timing(ctx);
         return BP_OK;
     }
 
@@ -436,6 +449,12 @@ int bp_ctx_synchronize(bp_ctx* ctx) {
 int bp_ctx_set_window_bits(bp_ctx* ctx, int c) {
     if (!ctx || c < 0 || c > 16 || c == 1) return BP_ERR_ARG;
     ctx->c_override = c;
+    return BP_OK;
+}
+
+int bp_ctx_set_device_tail(bp_ctx* ctx, int on) {
+    if (!ctx) return BP_ERR_ARG;
+    ctx->device_tail = on != 0;
     return BP_OK;
 }
 

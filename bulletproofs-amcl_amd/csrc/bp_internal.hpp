@@ -39,6 +39,7 @@ struct bp_ctx {
     hipStream_t stream = nullptr;
     int c_override = 0;
     bool timing = false;
+    bool device_tail = false;           // fold the window sums on the device (one lane) instead of on the host
     bool ipp_fold_generators = false;   // IPP prover: fold G/H each round (reference shape) instead of MSMs over the originals
     // MSM workspace
     DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_code, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, meta, partial, window_sum, scratch;

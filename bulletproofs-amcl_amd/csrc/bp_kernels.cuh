@@ -468,6 +468,26 @@ __global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __r
     if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
 }
 
+// ---------------------------------------------------------------------------------------------- device tail (optional)
+// sum_w 2^(off_w) S_w on the device: a strictly serial chain of ~bits doublings, executed by ONE lane.  Kept so that the
+// result can stay in HBM and to put a number on the design decision: ~2 ms here against ~0.13 ms for
+// the host fold (bp_host_tail.hpp).  out_le = canonical x || y little-endian words (all-zero = identity).
+template <class C>
+__global__ void __launch_bounds__(64) k_tail_fold(const XyzzPacked<C>* __restrict__ wsum, WinTab tab, int w_begin, int w_end, uint32_t* __restrict__ out_le) {
+    using Fp = typename C::Fp;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Xyzz<C> acc = xyzz_inf<C>();
+    for (int w = w_end - 1; w >= w_begin; w--) {
+        for (int i = 0; i < tab.cw[w]; i++) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, xyzz_unpack(wsum[w]));
+    }
+    Aff<C> a = xyzz_to_aff<C>(acc);
+    uint32_t xw[Fp::NW], yw[Fp::NW];
+    fe_pack_words<Fp>(xw, fe_from_mont<Fp>(a.x));
+    fe_pack_words<Fp>(yw, fe_from_mont<Fp>(a.y));
+    for (int k = 0; k < Fp::NW; k++) { out_le[k] = xw[k]; out_le[Fp::NW + k] = yw[k]; }
+}
+
 // ---------------------------------------------------------------------------------------------- conversions
 // canonical LE words (x || y per point) <-> resident packed Montgomery affine
 template <class C>

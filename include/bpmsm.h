@@ -73,7 +73,11 @@ int bp_ctx_destroy(bp_ctx* ctx);
 int bp_ctx_set_stream(bp_ctx* ctx, void* hip_stream);
 /* Block until everything queued on the context's stream has finished. */
 int bp_ctx_synchronize(bp_ctx* ctx);
-/* Pippenger window width in bits (1..16) for subsequent MSMs; 0 = choose from n (default). */
+/* Where bp_msm_g1 / bp_msm_g1_range fold the W window sums into the result (sum_w 2^off_w S_w, a serial chain of ~255
+ * doublings): 0 (default) on the host in ~0.13 ms; 1 on the device by a single lane (~2 ms; nothing but the final
+ * 2*fp_bytes leaves HBM).  Same bytes either way. */
+int bp_ctx_set_device_tail(bp_ctx* ctx, int on);
+/* Pippenger window width in bits (2..16) for subsequent MSMs; 0 = choose from n (default). */
 int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 
 /* ---- G1Vector --------------------------------------------------------------------------------------------- */
@@ -125,7 +129,9 @@ int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1
  * caller-owned HBM buffer.  The caller all-gathers the N ranks' records over RCCL (point addition is not an RCCL
  * reduction op; N*W*192 B is latency-bound).  Stage 2 (bp_msm_g1_finish): one D2H copy of `sets`
  * record sets, per-window sum, the serial 2^(c w) fold and the affine normalisation, giving BP_FMT_LE bytes.
- * All ranks must use the same n_per_set (or the same bp_ctx_set_window_bits) so that window geometry agrees. */
+ * All ranks must use the same n_per_set (or the same bp_ctx_set_window_bits) so that window geometry agrees.
+ * bp_msm_g1_windows returns after the records are complete in device_out (it synchronises the context's stream), so they
+ * can be handed to a collective on any other stream; the caller must in turn complete the gather before bp_msm_g1_finish. */
 size_t bp_msm_window_records(bp_ctx* ctx, size_t n);
 size_t bp_msm_record_bytes(int curve_id);
 int bp_msm_g1_windows(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n,

@@ -25,6 +25,8 @@ def main():
     cs = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
     ctx = bp.Context(curve, 0)
     ctx.enable_timing(True)
+    if os.environ.get("BP_DEVICE_TAIL"):
+        ctx.set_device_tail(True)
     for lg in lgs:
         n = 1 << lg
         kv = bp.FieldElementVector.from_bytes(ctx, rand_scalars(ctx, n, 1), n)

@@ -76,6 +76,20 @@ def test_msm_every_window_width(bp, ctxs, golden, name):
 
 
 @pytest.mark.parametrize("name", CURVES)
+def test_device_tail_gives_the_same_bytes(bp, ctxs, golden, name):
+    ctx = ctxs[name]
+    try:
+        ctx.set_device_tail(True)
+        for c in golden("msm")[name]:
+            n = c["n"]
+            pts = bp.G1Vector.from_bytes(ctx, b"".join(hx(p) for p in c["points"]), n)
+            sc = bp.FieldElementVector.from_bytes(ctx, b"".join(hx(s) for s in c["scalars"]), n)
+            assert pts.multi_scalar_mul_var_time(sc) == hx(c["out"]), c["name"]
+    finally:
+        ctx.set_device_tail(False)
+
+
+@pytest.mark.parametrize("name", CURVES)
 def test_length_mismatch_is_value_error(bp, ctxs, name):
     ctx = ctxs[name]
     g = O.generator(ctx.curve)

@@ -35,7 +35,7 @@ want = O.msm(curve, pts, ss, n, algo=O.PIPPENGER)
 assert acc == want, "sharded sum differs"
 t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == world
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+sys.stdout.write("rank-%d-ok\n" % rank); sys.stdout.flush()
 '''
 
 
@@ -61,4 +61,4 @@ def test_two_rank_gloo_sharded_msm(tmp_path):
            "--master-port", "29517", str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert "rank 0 ok" in p.stdout and "rank 1 ok" in p.stdout
+    assert "rank-0-ok" in p.stdout and "rank-1-ok" in p.stdout
