@@ -35,7 +35,7 @@ want = O.msm(curve, pts, ss, n, algo=O.PIPPENGER)
 assert acc == want, "sharded sum differs"
 t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == world
 dist.barrier(); dist.destroy_process_group()
-sys.stdout.write("rank-%d-ok\n" % rank); sys.stdout.flush()
+sys.stdout.write("rank-%%d-ok\n" %% rank); sys.stdout.flush()
 '''
 
 
