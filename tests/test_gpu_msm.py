@@ -208,3 +208,74 @@ def test_two_stage_sharded_msm(bp, ctxs, name):
     got = bp.msm_finish(ctx, buf.data_ptr(), 2, half)
     assert got == pts.multi_scalar_mul_var_time(sv)
     assert got == O.msm(ctx.curve, pts.to_bytes(), ss, n, algo=O.PIPPENGER, nthreads=8)
+
+
+def test_two_contexts_in_concurrent_threads(bp):
+    """One bp_ctx per host thread (include/bpmsm.h): the reference's tests run on parallel threads."""
+    import threading
+    results, errors = {}, []
+
+    def worker(tid, curve):
+        try:
+            ctx = bp.Context(curve, 0)
+            n = 3000 + 500 * tid
+            ks = O.random_scalars(curve, 900 + tid, n)
+            ss = O.random_scalars(curve, 950 + tid, n)
+            pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+            sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+            outs = [pts.multi_scalar_mul_var_time(sv) for _ in range(5)]
+            results[tid] = (curve, pts.to_bytes(), ss, n, outs)
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t, t % 2)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tid, (curve, host, ss, n, outs) in results.items():
+        want = O.msm(curve, host, ss, n, algo=O.PIPPENGER, nthreads=4)
+        assert all(o == want for o in outs), tid
+
+
+def test_caller_owned_stream(bp):
+    """bp_ctx_set_stream: kernels run on a torch side stream the caller owns."""
+    import torch
+    ctx = bp.Context(bp.BLS12_381, 0)
+    side = torch.cuda.Stream(device="cuda:0")
+    ctx.set_stream(side.cuda_stream)
+    n = 5000
+    ks, ss = O.random_scalars(0, 70, n), O.random_scalars(0, 71, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    got = pts.multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, ss, n))
+    assert got == O.g1_mul(0, O.fr_inner(0, ks, ss, n), O.generator(0))
+    ctx.set_stream(0)
+    assert pts.multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, ss, n)) == got
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_heavy_skew_2e18(bp, ctxs, name):
+    """Structured scalars at 2^18: one value repeated (every window has a single bucket with all the points), bit
+    vectors, and 16 distinct values -- the heavy-bucket / combine paths at scale; checked by linearity."""
+    import time
+    ctx = ctxs[name]
+    n = 1 << 18
+    ks = O.random_scalars(ctx.curve, 333, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    gen = O.generator(ctx.curve)
+    import random
+    rnd = random.Random(5)
+    vals16 = [rnd.getrandbits(250) for _ in range(16)]
+    for label, vals in (("all_equal", [0x1234567890ABCDEF1234567] * n), ("bits", [rnd.getrandbits(1) for _ in range(n)]),
+                        ("sixteen_values", [vals16[rnd.randrange(16)] for _ in range(n)])):
+        ss = b"".join(v.to_bytes(32, "little") for v in vals)
+        sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+        t0 = time.time()
+        got = pts.multi_scalar_mul_var_time(sv)
+        dt = time.time() - t0
+        assert got == O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen), label
+        assert dt < 2.0, (label, dt)      # no pathological serialisation
+    pts.free()
