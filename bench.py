@@ -120,6 +120,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- extra (not `value`): the same K MSMs issued from two host threads, each with its own context / HIP stream.
+    # The bucket reduce is latency-bound (one wave per SIMD), so a second MSM in flight fills the idle lanes.
+    overlapped = None
+    if not use_dist:
+        import threading
+        ctxs2 = [bp.Context(curve, local_rank) for _ in range(2)]
+        views = [(bp.G1Vector.wrap_device(c, pts.device_ptr(), n), bp.FieldElementVector.wrap_device(c, sv.device_ptr(), n)) for c in ctxs2]
+        for p2, s2 in views:
+            p2.multi_scalar_mul_var_time(s2)
+        per_thread = max(1, args.steps // 2)
+        res2 = [None, None]
+
+        def work(i):
+            p2, s2 = views[i]
+            for _ in range(per_thread):
+                res2[i] = p2.multi_scalar_mul_var_time(s2)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        torch.cuda.synchronize(dev)
+        el2 = time.perf_counter() - t0
+        overlapped = {"streams": 2, "steps": 2 * per_thread, "ms_per_step": el2 / (2 * per_thread) * 1e3, "value": n * 2 * per_thread / el2,
+                      "unit": "scalar-muls/s", "same_result": bool(res2[0] == result and res2[1] == result)}
+        for c in ctxs2:
+            c.close()
+
     # ---- dominant-kernel roofline: HIP events on the kernel's own stream, separate passes ------------------------
     ctx.enable_timing(True)
     acc_ms, dev_ms = [], []
@@ -172,6 +203,7 @@ def main():
                        "sharding": "index range per rank, all_gather of %d window records/rank over RCCL" % W if use_dist else "single GPU"},
             "stages_ms": stages,
             "roofline": roofline,
+            "overlapped_2_streams": overlapped,
         }
 
     # ---- correctness of the timed result: MSM(s, k.G) == (<s,k> mod r).G  (oracle = checker only) ------------------
