@@ -9,10 +9,50 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "../bulletproofs-amcl_amd/csrc/bp_field.cuh"
-using namespace bp;
-using P = Bls381Fp;
-using F = Fe<P>;
+// Self-contained: the saturated 12x32 formulations A and B are kept here only for the comparison; the product's
+// field layer (bulletproofs-amcl_amd/csrc/bp_field.cuh) is formulation C.
+struct P {
+    static constexpr int N = 12;
+    static constexpr uint32_t INV = 0xfffcfffdu;
+    static constexpr uint32_t MOD[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                         0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+};
+struct F { uint32_t v[12]; };
+
+template <class PP> __host__ __device__ __forceinline__ void fe_cond_sub(uint32_t* a, uint32_t hi) {
+    uint32_t t[PP::N];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < PP::N; i++) { uint64_t d = (uint64_t)a[i] - PP::MOD[i] - br; t[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    bool ge = (br == 0) || (hi != 0);
+#pragma unroll
+    for (int i = 0; i < PP::N; i++) a[i] = ge ? t[i] : a[i];
+}
+
+// A: saturated CIOS, plain C++
+__host__ __device__ __forceinline__ F fe_mul(const F& a, const F& b) {
+    constexpr int N = P::N;
+    uint32_t t[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 2; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) { c = (uint64_t)a.v[j] * b.v[i] + t[j] + c; t[j] = (uint32_t)c; c >>= 32; }
+        c += t[N]; t[N] = (uint32_t)c; t[N + 1] = (uint32_t)(c >> 32);
+        uint32_t m = t[0] * P::INV;
+        c = (uint64_t)m * P::MOD[0] + t[0]; c >>= 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) { c = (uint64_t)m * P::MOD[j] + t[j] + c; t[j - 1] = (uint32_t)c; c >>= 32; }
+        c += t[N]; t[N - 1] = (uint32_t)c; t[N] = t[N + 1] + (uint32_t)(c >> 32);
+    }
+    F r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    fe_cond_sub<P>(r.v, t[N]);
+    return r;
+}
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
