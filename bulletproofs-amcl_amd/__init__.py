@@ -90,6 +90,8 @@ SYMBOLS = {
     "bp_msm_g1": (_I, [_P, _P, _P, _U8P]),
     "bp_msm_g1_range": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _U8P]),
     "bp_msm_g1_pair": (_I, [_P, _P, _P, _P, _U8P, _U8P]),
+    "bp_msm_g1_begin": (_I, [_P, _P, _P]),
+    "bp_msm_g1_end": (_I, [_P, _U8P]),
     "bp_msm_window_records": (_SZ, [_P, _SZ]),
     "bp_msm_record_bytes": (_SZ, [_I]),
     "bp_msm_g1_windows": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _P]),
@@ -276,6 +278,15 @@ class G1Vector:
 
     inner_product_var_time = multi_scalar_mul_var_time
     inner_product_const_time = multi_scalar_mul_var_time
+
+    def msm_begin(self, scalars):
+        """queue the MSM on this vector's context; finish with msm_end() (one in flight per context)"""
+        _check(lib().bp_msm_g1_begin(self.ctx.h, self.h, scalars.h), "bp_msm_g1_begin")
+
+    def msm_end(self):
+        out = ctypes.create_string_buffer(self.ctx.point_bytes)
+        _check(lib().bp_msm_g1_end(self.ctx.h, out), "bp_msm_g1_end")
+        return out.raw
 
     def multi_scalar_mul_pair(self, scalars1, scalars2):
         """(<s1, P>, <s2, P>) in one pipeline pass"""

@@ -282,6 +282,32 @@ struct Impl {
         return BP_OK;
     }
 
+    // Asynchronous form of msm(): begin() queues the device pipeline and the D2H copy of the window sums on the
+    // context's stream and returns; end() waits for them and runs the host tail.  One MSM in flight per context.
+    static int msm_begin(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n) {
+        ctx->pending = false;
+        ctx->pending_n = n;
+        if (n == 0) { ctx->pending = true; return BP_OK; }
+        MsmGeom g;
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
+        if (rc) return rc;
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pending = true;
+        return BP_OK;
+    }
+    static int msm_end(bp_ctx* ctx, uint8_t* out_le) {
+        if (!ctx->pending) return BP_ERR_ARG;
+        ctx->pending = false;
+        if (ctx->pending_n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
+        MsmGeom g;
+        msm_geom(g, C::Fr::BITS, ctx->pending_n, ctx->c_override);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        collect_timing(ctx);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, g.tab.W, g.tab.cw, out_le);
+        return BP_OK;
+    }
+
     // Two scalar sets over the same points in ONE pipeline pass (2W windows): out1 = <sc1, pts>, out2 = <sc2, pts>.
     static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le, size_t nnz = 0) {
         if (n == 0) { memset(out1_le, 0, 2 * 4 * Fp::NW); memset(out2_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
@@ -633,6 +659,19 @@ int bp_msm_g1(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars, uint
     if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
     if (points->n != scalars->n) return BP_ERR_LENGTH;
     return bp_msm_g1_range(ctx, points, 0, scalars, 0, points->n, out_le);
+}
+
+int bp_msm_g1_begin(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars) {
+    if (!ctx || !points || !scalars) return BP_ERR_ARG;
+    if (points->n != scalars->n) return BP_ERR_LENGTH;
+    int rc = set_device(ctx); if (rc) return rc;
+    DISPATCH(ctx, I::msm_begin(ctx, points->d, 0, scalars->d, 0, points->n));
+}
+
+int bp_msm_g1_end(bp_ctx* ctx, uint8_t* out_le) {
+    if (!ctx || !out_le) return BP_ERR_ARG;
+    int rc = set_device(ctx); if (rc) return rc;
+    DISPATCH(ctx, I::msm_end(ctx, out_le));
 }
 
 int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1, const bp_frvec* scalars2, uint8_t* out1_le, uint8_t* out2_le) {

@@ -39,6 +39,8 @@ struct bp_ctx {
     hipStream_t stream = nullptr;
     int c_override = 0;
     bool timing = false;
+    bool pending = false;               // bp_msm_g1_begin issued, bp_msm_g1_end not yet called
+    size_t pending_n = 0;
     bool device_tail = false;           // fold the window sums on the device (one lane) instead of on the host
     bool ipp_fold_generators = false;   // IPP prover: fold G/H each round (reference shape) instead of MSMs over the originals
     // MSM workspace

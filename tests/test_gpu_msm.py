@@ -279,3 +279,27 @@ def test_msm_heavy_skew_2e18(bp, ctxs, name):
         assert got == O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen), label
         assert dt < 2.0, (label, dt)      # no pathological serialisation
     pts.free()
+
+
+def test_begin_end_two_contexts_one_thread(bp):
+    """bp_msm_g1_begin / _end: two MSMs in flight from one host thread (two contexts, two streams)."""
+    ca, cb = bp.Context(bp.BLS12_381, 0), bp.Context(bp.BLS12_381, 0)
+    n = 40000
+    ks, s1, s2 = O.random_scalars(0, 81, n), O.random_scalars(0, 82, n), O.random_scalars(0, 83, n)
+    pa = bp.G1Vector.fixed_base(ca, bp.FieldElementVector.from_bytes(ca, ks, n))
+    ca.synchronize()
+    pb = bp.G1Vector.wrap_device(cb, pa.device_ptr(), n)
+    va, vb = bp.FieldElementVector.from_bytes(ca, s1, n), bp.FieldElementVector.from_bytes(cb, s2, n)
+    gen = O.generator(0)
+    w1, w2 = O.g1_mul(0, O.fr_inner(0, ks, s1, n), gen), O.g1_mul(0, O.fr_inner(0, ks, s2, n), gen)
+    for _ in range(3):
+        pa.msm_begin(va)
+        pb.msm_begin(vb)
+        assert pa.msm_end() == w1
+        assert pb.msm_end() == w2
+    with pytest.raises(bp.ArgError):
+        pa.msm_end()                       # nothing pending
+    empty = bp.G1Vector.new(ca, 0)
+    empty.msm_begin(bp.FieldElementVector.new(ca, 0))
+    assert empty.msm_end() == bytes(ca.point_bytes)
+    ca.close(); cb.close()
