@@ -372,6 +372,39 @@ struct Impl {
         return BP_OK;
     }
 
+    // table of d * 2^(4j) * G via the generic scalar-mul kernel (960 elements, once per context)
+    static int ensure_fixed_base_table(bp_ctx* ctx) {
+        if (ctx->fixed_base_ready) return BP_OK;
+        const size_t m = (size_t)kFixedBaseWindows * 15;
+        int rc;
+        if ((rc = ctx->fixed_base_table.reserve(m * kPointBytes))) return rc;
+        if ((rc = ctx->scratch.reserve(m * 32))) return rc;
+        std::vector<ScalarWords> ks(m);
+        for (int j = 0; j < kFixedBaseWindows; j++)
+            for (int d = 1; d <= 15; d++) {
+                ScalarWords s;
+                memset(&s, 0, sizeof s);
+                s.w[(4 * j) >> 5] = (uint32_t)d << ((4 * j) & 31);      // d * 2^(4j): a nibble never straddles a word
+                ks[(size_t)j * 15 + d - 1] = s;
+            }
+        HIPCHK(hipMemcpyAsync(ctx->scratch.p, ks.data(), m * 32, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_scalar_mul<C>, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)nullptr,
+                           (const ScalarWords*)ctx->scratch.p, m, (AffPacked<C>*)ctx->fixed_base_table.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // ks is a host temporary
+        ctx->fixed_base_ready = true;
+        return BP_OK;
+    }
+
+    static int fixed_base(bp_ctx* ctx, const void* k, size_t n, void* out) {
+        int rc = ensure_fixed_base_table(ctx);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_fixed_base<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const AffPacked<C>*)ctx->fixed_base_table.p, (const ScalarWords*)k, n, (AffPacked<C>*)out);
+        HIPCHK(hipGetLastError());
+        return BP_OK;
+    }
+
     static int scalar_mul(bp_ctx* ctx, const void* base, const void* k, size_t n, void* out) {
         hipLaunchKernelGGL(k_scalar_mul<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
                            (const AffPacked<C>*)base, (const ScalarWords*)k, n, (AffPacked<C>*)out);
@@ -450,6 +483,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     if (!ctx) return BP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->fixed_base_table.release();
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_code, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
                       &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch}) b->release();
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
@@ -588,8 +622,11 @@ int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1
     int rc = bp_g1vec_alloc(ctx, k->n, out);
     if (rc) return rc;
     if (k->n == 0) return BP_OK;
-    if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::scalar_mul(ctx, p ? p->d : nullptr, k->d, k->n, (*out)->d);
-    else rc = Impl<Bn254>::scalar_mul(ctx, p ? p->d : nullptr, k->d, k->n, (*out)->d);
+    if (!p) {   // fixed base: table of generator multiples
+        if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::fixed_base(ctx, k->d, k->n, (*out)->d);
+        else rc = Impl<Bn254>::fixed_base(ctx, k->d, k->n, (*out)->d);
+    } else if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::scalar_mul(ctx, p->d, k->d, k->n, (*out)->d);
+    else rc = Impl<Bn254>::scalar_mul(ctx, p->d, k->d, k->n, (*out)->d);
     if (rc) { bp_g1vec_free(*out); *out = nullptr; }
     return rc;
 }

@@ -44,6 +44,8 @@ struct bp_ctx {
     bool device_tail = false;           // fold the window sums on the device (one lane) instead of on the host
     bool ipp_fold_generators = false;   // IPP prover: fold G/H each round (reference shape) instead of MSMs over the originals
     // MSM workspace
+    DevBuf fixed_base_table;            // d * 2^(4j) * G, built on first use (bp_g1vec_fixed_base_mul)
+    bool fixed_base_ready = false;
     DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_code, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, meta, partial, window_sum, scratch;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;

@@ -530,4 +530,25 @@ __global__ void __launch_bounds__(kBlock) k_scalar_mul(const AffPacked<C>* __res
     out[i] = aff_pack(xyzz_to_aff<C>(r));
 }
 
+// out[i] = k[i] * G from a per-context table  T[j][d - 1] = d * 2^(4 j) * G  (j < 64, d = 1..15; 960 affine points):
+// 64 lazy mixed additions per element and no doubling at all.  (k_scalar_mul with base == nullptr does the same by
+// 255 doublings + ~128 additions per lane.)
+constexpr int kFixedBaseWindows = 64;
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fixed_base(const AffPacked<C>* __restrict__ table, const ScalarWords* __restrict__ k, size_t n,
+                                                       AffPacked<C>* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ScalarWords s = k[i];
+    uint64_t q0 = s.w[0] | ((uint64_t)s.w[1] << 32), q1 = s.w[2] | ((uint64_t)s.w[3] << 32), q2 = s.w[4] | ((uint64_t)s.w[5] << 32),
+             q3 = s.w[6] | ((uint64_t)s.w[7] << 32);
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+    for (int j = 0; j < kFixedBaseWindows; j++) {
+        uint32_t d = (uint32_t)q0 & 15;
+        q0 = (q0 >> 4) | (q1 << 60); q1 = (q1 >> 4) | (q2 << 60); q2 = (q2 >> 4) | (q3 << 60); q3 >>= 4;
+        if (d) xyzz_lazy_add_aff(acc, aff_unpack(table[j * 15 + (d - 1)]));
+    }
+    out[i] = aff_pack(xyzz_to_aff<C>(xyzz_lazy_to_strict(acc)));
+}
+
 }  // namespace bp
