@@ -1,0 +1,213 @@
+// include/bpmsm.hpp -- C++ host-side mirror of the reference's interface for the hot path, header-only, over the C ABI
+// of include/bpmsm.h.  (The reference is Rust; there is no Rust toolchain in the build image, so the compiled-language
+// host mirror is C++.)  Names, argument meaning and error behaviour follow the reference:
+//
+//   bp::FieldElementVector        amcl_wrapper::field_elem::FieldElementVector    inner_product, hadamard_product, scaled_by,
+//                                                                                 new_vandermonde_vector
+//   bp::G1Vector                  amcl_wrapper::group_elem_g1::G1Vector           multi_scalar_mul_var_time,
+//                                                                                 inner_product_var_time / _const_time
+//   bp::Transcript                merlin::Transcript + TranscriptProtocol         /root/reference src/transcript.rs:12-61
+//   bp::InnerProductArgumentProof /root/reference src/ipp.rs:13-20
+//   bp::IPP::create_ipp / verify_ipp / verification_scalars                       /root/reference src/ipp.rs:35-315
+//
+// Errors: amcl_wrapper's ValueError (length mismatch) -> bp::ValueError; the assert!s of create_ipp -> bp::ArgError
+// (the reference panics); R1CSError::VerificationError -> bp::VerificationError; HIP failures / no GPU -> bp::DeviceError.
+// Points are BP_FMT_LE byte strings (x || y little-endian), scalars 32-byte little-endian.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "bpmsm.h"
+
+namespace bp {
+
+using Bytes = std::vector<uint8_t>;
+
+struct Error : std::runtime_error { int code; Error(const std::string& w, int c) : std::runtime_error(w + " failed with status " + std::to_string(c)), code(c) {} };
+struct ValueError : Error { using Error::Error; };
+struct ArgError : Error { using Error::Error; };
+struct VerificationError : Error { using Error::Error; };
+struct DeviceError : Error { using Error::Error; };
+
+inline void check(int rc, const char* what) {
+    switch (rc) {
+        case BP_OK: return;
+        case BP_ERR_LENGTH: throw ValueError(what, rc);
+        case BP_ERR_ARG: throw ArgError(what, rc);
+        case BP_ERR_VERIFY: throw VerificationError(what, rc);
+        default: throw DeviceError(what, rc);
+    }
+}
+
+class Context {
+public:
+    explicit Context(int curve_id = BP_CURVE_BLS12_381, int device = 0) : curve_(curve_id) {
+        check(bp_ctx_create(curve_id, device, &h_), "bp_ctx_create");
+        bp_curve_info info;
+        check(bp_curve_params(curve_id, &info), "bp_curve_params");
+        point_bytes_ = 2 * (size_t)info.fp_bytes;
+    }
+    ~Context() { bp_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    bp_ctx* handle() const { return h_; }
+    int curve() const { return curve_; }
+    size_t point_bytes() const { return point_bytes_; }
+
+private:
+    bp_ctx* h_ = nullptr;
+    int curve_;
+    size_t point_bytes_;
+};
+
+class FieldElementVector {
+public:
+    FieldElementVector(Context& ctx, const Bytes& scalars_le32) : ctx_(&ctx) {
+        check(bp_frvec_upload(ctx.handle(), scalars_le32.data(), scalars_le32.size() / 32, &h_), "bp_frvec_upload");
+    }
+    FieldElementVector(Context& ctx, bp_frvec* owned) : ctx_(&ctx), h_(owned) {}
+    FieldElementVector(FieldElementVector&& o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+    FieldElementVector(const FieldElementVector&) = delete;
+    ~FieldElementVector() { bp_frvec_free(h_); }
+    static FieldElementVector new_vandermonde_vector(Context& ctx, const Bytes& e_le32, size_t n) {
+        bp_frvec* h = nullptr;
+        check(bp_fr_vandermonde(ctx.handle(), e_le32.data(), n, &h), "bp_fr_vandermonde");
+        return FieldElementVector(ctx, h);
+    }
+    size_t len() const { return bp_frvec_len(h_); }
+    Bytes to_bytes() const {
+        Bytes out(len() * 32);
+        check(bp_frvec_download(ctx_->handle(), h_, 0, len(), out.data()), "bp_frvec_download");
+        return out;
+    }
+    Bytes inner_product(const FieldElementVector& rhs) const {
+        if (len() != rhs.len()) throw ValueError("inner_product", BP_ERR_LENGTH);
+        Bytes out(32);
+        check(bp_fr_inner_product(ctx_->handle(), h_, 0, rhs.h_, 0, len(), out.data()), "bp_fr_inner_product");
+        return out;
+    }
+    FieldElementVector hadamard_product(const FieldElementVector& rhs) const {
+        bp_frvec* h = nullptr;
+        check(bp_fr_hadamard(ctx_->handle(), h_, rhs.h_, &h), "bp_fr_hadamard");
+        return FieldElementVector(*ctx_, h);
+    }
+    FieldElementVector scaled_by(const Bytes& s_le32) const {
+        bp_frvec* h = nullptr;
+        check(bp_fr_scaled_by(ctx_->handle(), h_, s_le32.data(), &h), "bp_fr_scaled_by");
+        return FieldElementVector(*ctx_, h);
+    }
+    bp_frvec* handle() const { return h_; }
+
+private:
+    Context* ctx_;
+    bp_frvec* h_ = nullptr;
+};
+
+class G1Vector {
+public:
+    G1Vector(Context& ctx, const Bytes& points_le) : ctx_(&ctx) {
+        check(bp_g1vec_upload(ctx.handle(), points_le.data(), points_le.size() / ctx.point_bytes(), BP_FMT_LE, &h_), "bp_g1vec_upload");
+    }
+    G1Vector(Context& ctx, bp_g1vec* owned) : ctx_(&ctx), h_(owned) {}
+    G1Vector(G1Vector&& o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+    G1Vector(const G1Vector&) = delete;
+    ~G1Vector() { bp_g1vec_free(h_); }
+    // [k_i * G]: stand-in generator vectors (the reference's get_generators hashes to the curve, src/utils/mod.rs:16-23)
+    static G1Vector fixed_base(Context& ctx, const FieldElementVector& k) {
+        bp_g1vec* h = nullptr;
+        check(bp_g1vec_fixed_base_mul(ctx.handle(), k.handle(), &h), "bp_g1vec_fixed_base_mul");
+        return G1Vector(ctx, h);
+    }
+    size_t len() const { return bp_g1vec_len(h_); }
+    Bytes to_bytes() const {
+        Bytes out(len() * ctx_->point_bytes());
+        check(bp_g1vec_download(ctx_->handle(), h_, 0, len(), BP_FMT_LE, out.data()), "bp_g1vec_download");
+        return out;
+    }
+    Bytes multi_scalar_mul_var_time(const FieldElementVector& scalars) const {
+        Bytes out(ctx_->point_bytes());
+        check(bp_msm_g1(ctx_->handle(), h_, scalars.handle(), out.data()), "bp_msm_g1");
+        return out;
+    }
+    Bytes inner_product_var_time(const FieldElementVector& s) const { return multi_scalar_mul_var_time(s); }
+    Bytes inner_product_const_time(const FieldElementVector& s) const { return multi_scalar_mul_var_time(s); }
+    bp_g1vec* handle() const { return h_; }
+
+private:
+    Context* ctx_;
+    bp_g1vec* h_ = nullptr;
+};
+
+class Transcript {
+public:
+    explicit Transcript(const std::string& label) { check(bp_transcript_new((const uint8_t*)label.data(), label.size(), &h_), "bp_transcript_new"); }
+    ~Transcript() { bp_transcript_free(h_); }
+    Transcript(const Transcript&) = delete;
+    void append_message(const std::string& label, const Bytes& msg) {
+        check(bp_transcript_append_message(h_, (const uint8_t*)label.data(), label.size(), msg.data(), msg.size()), "append_message");
+    }
+    Bytes challenge_bytes(const std::string& label, size_t n) {
+        Bytes out(n);
+        check(bp_transcript_challenge_bytes(h_, (const uint8_t*)label.data(), label.size(), out.data(), n), "challenge_bytes");
+        return out;
+    }
+    void commit_point(int curve, const char* label, const Bytes& p) { check(bp_transcript_commit_point(h_, curve, label, p.data()), "commit_point"); }
+    void commit_scalar(int curve, const char* label, const Bytes& s) { check(bp_transcript_commit_scalar(h_, curve, label, s.data()), "commit_scalar"); }
+    Bytes challenge_scalar(int curve, const char* label) {
+        Bytes out(32);
+        check(bp_transcript_challenge_scalar(h_, curve, label, out.data()), "challenge_scalar");
+        return out;
+    }
+    bp_transcript* handle() const { return h_; }
+
+private:
+    bp_transcript* h_ = nullptr;
+};
+
+struct InnerProductArgumentProof {   // src/ipp.rs:13-20
+    Bytes L, R;                      // lg n points each, BP_FMT_LE
+    Bytes a, b;                      // 32-byte LE scalars
+};
+
+struct IPP {
+    // src/ipp.rs:35-202
+    static InnerProductArgumentProof create_ipp(Context& ctx, Transcript& transcript, const Bytes& Q, const FieldElementVector& G_factors,
+                                                const FieldElementVector& H_factors, const G1Vector& G_vec, const G1Vector& H_vec,
+                                                const FieldElementVector& a_vec, const FieldElementVector& b_vec) {
+        size_t n = G_vec.len(), lg = 0;
+        InnerProductArgumentProof p;
+        p.L.resize(64 * ctx.point_bytes());
+        p.R.resize(64 * ctx.point_bytes());
+        p.a.resize(32);
+        p.b.resize(32);
+        check(bp_ipp_create(ctx.handle(), transcript.handle(), Q.data(), G_factors.handle(), H_factors.handle(), G_vec.handle(), H_vec.handle(),
+                            a_vec.handle(), b_vec.handle(), p.L.data(), p.R.data(), &lg, p.a.data(), p.b.data()),
+              "bp_ipp_create");
+        (void)n;
+        p.L.resize(lg * ctx.point_bytes());
+        p.R.resize(lg * ctx.point_bytes());
+        return p;
+    }
+    // src/ipp.rs:204-260: returns on success, throws VerificationError otherwise (Result<(), R1CSError>)
+    static void verify_ipp(Context& ctx, size_t n, Transcript& transcript, const FieldElementVector& G_factors, const FieldElementVector& H_factors,
+                           const Bytes& P, const Bytes& Q, const G1Vector& G, const G1Vector& H, const Bytes& a, const Bytes& b, const Bytes& L_vec,
+                           const Bytes& R_vec) {
+        check(bp_ipp_verify(ctx.handle(), transcript.handle(), n, G_factors.handle(), H_factors.handle(), P.data(), Q.data(), G.handle(), H.handle(),
+                            a.data(), b.data(), L_vec.data(), R_vec.data(), L_vec.size() / ctx.point_bytes()),
+              "bp_ipp_verify");
+    }
+    // src/ipp.rs:262-315: (u_sq, u_inv_sq, s)
+    static void verification_scalars(int curve, size_t point_bytes, const Bytes& L_vec, const Bytes& R_vec, size_t n, Transcript& transcript, Bytes& u_sq,
+                                     Bytes& u_inv_sq, Bytes& s) {
+        size_t lg = L_vec.size() / point_bytes;
+        u_sq.assign(lg * 32 + 32, 0); u_inv_sq.assign(lg * 32 + 32, 0); s.assign(n * 32 + 32, 0);
+        check(bp_ipp_verification_scalars(curve, transcript.handle(), L_vec.data(), R_vec.data(), lg, n, u_sq.data(), u_inv_sq.data(), s.data()),
+              "bp_ipp_verification_scalars");
+        u_sq.resize(lg * 32); u_inv_sq.resize(lg * 32); s.resize(n * 32);
+    }
+};
+
+}  // namespace bp
