@@ -80,6 +80,8 @@ SYMBOLS = {
     "bp_g1vec_wrap_device": (_I, [_P, _P, _SZ, _PP]),
     "bp_g1vec_fixed_base_mul": (_I, [_P, _P, _PP]),
     "bp_g1vec_scalar_mul": (_I, [_P, _P, _P, _PP]),
+    "bp_g1vec_from_msg_hash": (_I, [_P, _U8P, _P, _SZ, _PP]),
+    "bp_get_generators": (_I, [_P, _U8P, _SZ, ctypes.c_uint64, _SZ, _PP]),
     "bp_frvec_upload": (_I, [_P, _U8P, _SZ, _PP]),
     "bp_frvec_alloc": (_I, [_P, _SZ, _PP]),
     "bp_frvec_download": (_I, [_P, _P, _SZ, _SZ, _U8P]),
@@ -251,6 +253,18 @@ class G1Vector:
         _check(lib().bp_g1vec_fixed_base_mul(ctx.h, scalars.h, ctypes.byref(h)), "bp_g1vec_fixed_base_mul")
         return cls(ctx, h)
 
+    @classmethod
+    def from_msg_hash(cls, ctx, messages):
+        """[G1::from_msg_hash(m) for m in messages] (amcl_wrapper), hashed and mapped on the device."""
+        messages = [bytes(m) for m in messages]
+        offs = (ctypes.c_uint64 * (len(messages) + 1))()
+        for i, m in enumerate(messages):
+            offs[i + 1] = offs[i] + len(m)
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_from_msg_hash(ctx.h, b"".join(messages), ctypes.cast(offs, ctypes.c_void_p), len(messages), ctypes.byref(h)),
+               "bp_g1vec_from_msg_hash")
+        return cls(ctx, h)
+
     def scaled_by(self, scalars):
         """[k_i * P_i]"""
         h = ctypes.c_void_p()
@@ -361,6 +375,15 @@ class FieldElementVector:
             self.free()
         except Exception:
             pass
+
+
+def get_generators(ctx, prefix, n, first=1):
+    """utils::get_generators(prefix, n) (reference src/utils/mod.rs:16-23): [from_msg_hash(prefix || str(i)) for i in 1..=n],
+    returned resident in HBM.  `first` shifts the counter (rank r of a sharded setup generates its own index range)."""
+    prefix = prefix.encode() if isinstance(prefix, str) else bytes(prefix)
+    h = ctypes.c_void_p()
+    _check(lib().bp_get_generators(ctx.h, prefix, len(prefix), first, n, ctypes.byref(h)), "bp_get_generators")
+    return G1Vector(ctx, h)
 
 
 def msm_windows(ctx, points, poff, scalars, soff, n, device_out_ptr):

@@ -1,0 +1,85 @@
+// bp_capi_hash.hip -- C ABI for hash-to-G1 (include/bpmsm.h: bp_g1vec_from_msg_hash, bp_get_generators).
+// Kernels: bp_hash.cuh.  Reference call sites: src/utils/mod.rs:16-23 (get_generators) and G1::from_msg_hash in the
+// gadget tests (e.g. src/r1cs/gadgets/bound_check.rs:200-203).
+#include <vector>
+
+#include "bp_internal.hpp"
+#include "bp_hash.cuh"
+
+using namespace bp;
+
+namespace {
+
+template <class C> SqrtExp sqrt_exponent() {   // (p + 1) / 4 from the modulus words
+    using W = typename C::Fp::Words;
+    constexpr int NW = C::Fp::NW;
+    uint32_t t[12] = {};
+    uint64_t carry = 1;
+    for (int i = 0; i < NW; i++) { uint64_t v = (uint64_t)W::MODW[i] + carry; t[i] = (uint32_t)v; carry = v >> 32; }
+    SqrtExp e{};
+    for (int i = 0; i < NW; i++) e.w[i] = (t[i] >> 2) | (i + 1 < NW ? t[i + 1] << 30 : (uint32_t)carry << 30);
+    return e;
+}
+
+template <class C>
+int launch_hash(bp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offs, uint32_t prefix_len, uint64_t first, size_t n, void* out) {
+    static_assert((C::Fp::Words::MODW[0] & 3) == 3, "sqrt by (p+1)/4 needs p = 3 mod 4");
+    unsigned grid = (unsigned)((n + kHashBlock - 1) / kHashBlock);
+    hipLaunchKernelGGL(k_hash_to_g1<C>, dim3(grid), dim3(kHashBlock), 0, ctx->stream, d_bytes, d_offs, prefix_len, first, n, sqrt_exponent<C>(),
+                       (AffPacked<C>*)out);
+    HIPCHK(hipGetLastError());
+    BP_TRACE_SYNC(ctx, "k_hash_to_g1<C>");
+    return BP_OK;
+}
+
+// bytes (+ optional offsets) -> device scratch, launch, wait (the staging buffers are freed on return)
+int hash_common(bp_ctx* ctx, const uint8_t* bytes, size_t nbytes, const uint64_t* offs, uint64_t first, size_t n, bp_g1vec** out) {
+    int rc = bp_g1vec_alloc(ctx, n, out);
+    if (rc) return rc;
+    if (n == 0) return BP_OK;
+    void *d_bytes = nullptr, *d_offs = nullptr;
+    auto fail = [&](int code) { if (d_bytes) (void)hipFree(d_bytes); if (d_offs) (void)hipFree(d_offs); bp_g1vec_free(*out); *out = nullptr; return code; };
+    if (hipMalloc(&d_bytes, nbytes ? nbytes : 1) != hipSuccess) return fail(BP_ERR_DEVICE);
+    if (nbytes && hipMemcpyAsync(d_bytes, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(BP_ERR_DEVICE);
+    if (offs) {
+        if (hipMalloc(&d_offs, (n + 1) * sizeof(uint64_t)) != hipSuccess) return fail(BP_ERR_DEVICE);
+        if (hipMemcpyAsync(d_offs, offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(BP_ERR_DEVICE);
+    }
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = launch_hash<Bls381>(ctx, (const uint8_t*)d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (*out)->d);
+    else rc = launch_hash<Bn254>(ctx, (const uint8_t*)d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (*out)->d);
+    if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_DEVICE;
+    if (rc) return fail(rc);
+    (void)hipFree(d_bytes);
+    if (d_offs) (void)hipFree(d_offs);
+    return BP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bp_g1vec_from_msg_hash(bp_ctx* ctx, const uint8_t* msgs, const uint64_t* offsets, size_t n, bp_g1vec** out) {
+    if (!ctx || !out || (n && !offsets)) return BP_ERR_ARG;
+    *out = nullptr;
+    size_t total = 0;
+    if (n) {
+        if (offsets[0] != 0) return BP_ERR_ARG;
+        for (size_t i = 0; i < n; i++) {
+            if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0x7fffffffull) return BP_ERR_ARG;
+        }
+        total = (size_t)offsets[n];
+        if (total && !msgs) return BP_ERR_ARG;
+    }
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    return hash_common(ctx, msgs, total, offsets, 0, n, out);
+}
+
+int bp_get_generators(bp_ctx* ctx, const uint8_t* prefix, size_t prefix_len, uint64_t first, size_t n, bp_g1vec** out) {
+    if (!ctx || !out || (prefix_len && !prefix) || prefix_len > 0x7fffffffull) return BP_ERR_ARG;
+    *out = nullptr;
+    if (n && first + (n - 1) < first) return BP_ERR_ARG;   // the counter must not wrap
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    return hash_common(ctx, prefix, prefix_len, nullptr, first, n, out);
+}
+
+}  // extern "C"

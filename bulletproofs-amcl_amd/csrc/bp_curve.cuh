@@ -25,6 +25,8 @@ struct Bls381 {
     static constexpr int ID = 0;
     static constexpr int MODBYTES = 48;   // amcl MODBYTES
     static constexpr uint32_t B = 4;
+    static constexpr bool COFACTOR_IS_ONE = false;
+    static constexpr uint32_t COFACTOR[4] = {0x0000aaabu, 0x8c00aaabu, 0x5555e156u, 0x396c8c00u};   // (x-1)^2/3, amcl rom CURVE_COF
     static constexpr uint32_t GX[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
                                         0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
     static constexpr uint32_t GY[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
@@ -37,6 +39,8 @@ struct Bn254 {
     static constexpr int ID = 1;
     static constexpr int MODBYTES = 32;
     static constexpr uint32_t B = 2;
+    static constexpr bool COFACTOR_IS_ONE = true;
+    static constexpr uint32_t COFACTOR[4] = {1, 0, 0, 0};
     static constexpr uint32_t GX[8] = {0x00000012u, 0xa7000000u, 0x00000013u, 0x61210000u, 0x00000008u, 0xba344d80u, 0x40000001u, 0x25236482u};
     static constexpr uint32_t GY[8] = {0x00000001u, 0, 0, 0, 0, 0, 0, 0};
 };

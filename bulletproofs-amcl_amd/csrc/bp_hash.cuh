@@ -1,0 +1,182 @@
+// bp_hash.cuh -- hash-to-G1 on the device: one lane per message.
+//
+// Replaces amcl_wrapper `G1::from_msg_hash(msg)` = `GroupG1::mapit(&hash_msg(msg))`, the call behind
+// `get_generators(prefix, n)` (reference src/utils/mod.rs:16-23) and the `g`, `h` of the gadget tests
+// (e.g. src/r1cs/gadgets/bound_check.rs:200-203).  The crates are not vendored; the map is restated from the
+// published amcl algorithm [UNVERIFIED-RECALL]; the tests check it against two independent CPU restatements:
+//     h = SHAKE256(msg)[0 .. MODBYTES)            x = BE(h) mod p
+//     loop:  rhs = x^3 + b;  found = rhs is a non-zero square;  y = the EVEN square root;  x += 1
+//            if found: P = cofactor * (x_old, y);  if P != O: return P
+// Both base fields have p = 3 (mod 4), so sqrt(rhs) = rhs^((p+1)/4) and one exponentiation answers both questions.
+//
+// Cost per point (BLS12-381): ~2 tries * ~570 Fp-mul (exponentiation) + 126 doublings and ~60 additions for the
+// cofactor + one inversion (~570) -- ALU-bound like the rest of the library; SHAKE256 is one Keccak-f per message.
+#pragma once
+#include "bp_curve.cuh"
+
+namespace bp {
+
+constexpr int kHashBlock = 256;
+
+__device__ __constant__ const uint64_t kKeccakRC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+    0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+    0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// Keccak-f[1600], state in 25 named-by-index registers (every index below is a compile-time constant after unrolling).
+__device__ __forceinline__ void keccak_f1600_dev(uint64_t (&a)[25]) {
+    constexpr int rho[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    constexpr int pi[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int r = 0; r < 24; r++) {
+        uint64_t bc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) bc[i] = a[i] ^ a[i + 5] ^ a[i + 10] ^ a[i + 15] ^ a[i + 20];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
+#pragma unroll
+            for (int j = 0; j < 25; j += 5) a[j + i] ^= t;
+        }
+        uint64_t t = a[1];
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            uint64_t b = a[pi[i]];
+            a[pi[i]] = rotl64(t, rho[i]);
+            t = b;
+        }
+#pragma unroll
+        for (int j = 0; j < 25; j += 5) {
+            uint64_t c0 = a[j], c1 = a[j + 1], c2 = a[j + 2], c3 = a[j + 3], c4 = a[j + 4];
+            a[j] = c0 ^ (~c1 & c2);
+            a[j + 1] = c1 ^ (~c2 & c3);
+            a[j + 2] = c2 ^ (~c3 & c4);
+            a[j + 3] = c3 ^ (~c4 & c0);
+            a[j + 4] = c4 ^ (~c0 & c1);
+        }
+        a[0] ^= kKeccakRC[r];
+    }
+}
+
+// A message = prefix bytes followed by tail bytes (either the decimal digits of a counter, or nothing).
+struct HashMsg {
+    const uint8_t* head;
+    uint32_t head_len;
+    uint8_t tail[20];
+    uint32_t tail_len;
+    __device__ __forceinline__ uint32_t len() const { return head_len + tail_len; }
+    // byte j of the padded SHAKE256 input (suffix 0x1f at len; the closing 0x80 is xored in by the caller)
+    __device__ __forceinline__ uint64_t padded(uint32_t j) const {
+        if (j < head_len) return head[j];
+        uint32_t k = j - head_len;
+        if (k < tail_len) return tail[k < 20 ? k : 0];
+        return k == tail_len ? 0x1f : 0;
+    }
+};
+
+constexpr int kShakeRate = 136;
+
+// SHAKE256(msg) -> the first 64 output bytes as 8 little-endian lanes (MODBYTES <= 48 is all anyone asks for).
+__device__ __forceinline__ void shake256_dev(const HashMsg& m, uint64_t (&out)[8]) {
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = 0;
+    uint32_t nblocks = m.len() / kShakeRate + 1;
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        uint32_t base = blk * kShakeRate;
+#pragma unroll
+        for (int l = 0; l < kShakeRate / 8; l++) {
+            uint64_t w = 0;
+            for (int k = 0; k < 8; k++) w |= m.padded(base + 8 * l + k) << (8 * k);
+            a[l] ^= w;
+        }
+        if (blk + 1 == nblocks) a[kShakeRate / 8 - 1] ^= 0x8000000000000000ull;
+        keccak_f1600_dev(a);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = a[i];
+}
+
+__device__ __forceinline__ uint64_t bswap64_dev(uint64_t v) { return __builtin_bswap64(v); }
+
+// (p + 1) / 4 as canonical words, computed on the host from the modulus and passed by value.
+struct SqrtExp { uint32_t w[12]; };
+
+template <class P> __device__ __noinline__ Fe<P> fe_pow_words(const Fe<P>& a, const SqrtExp& e) {
+    Fe<P> acc = fe_one<P>();
+    for (int i = P::BITS - 1; i >= 0; i--) {
+        acc = fe_sqr<P>(acc);
+        if ((e.w[i >> 5] >> (i & 31)) & 1) acc = fe_mul<P>(acc, a);
+    }
+    return acc;
+}
+
+template <class C> __device__ Aff<C> hash_to_g1(const HashMsg& m, const SqrtExp& e) {
+    using Fp = typename C::Fp;
+    uint64_t lanes[8];
+    shake256_dev(m, lanes);
+    // BE(h): the last hash byte is the least significant byte of x
+    constexpr int NLANE = C::MODBYTES / 8;
+    uint32_t xw[Fp::NW];
+#pragma unroll
+    for (int l = 0; l < NLANE; l++) {
+        uint64_t v = bswap64_dev(lanes[NLANE - 1 - l]);
+        xw[2 * l] = (uint32_t)v;
+        xw[2 * l + 1] = (uint32_t)(v >> 32);
+    }
+    // x < 2^(8 MODBYTES) < R: the Montgomery product with R^2 mod p reduces it (pre-subtraction value < p + p/64)
+    Fe<Fp> x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
+    Fe<Fp> braw = fe_zero<Fp>();
+    braw.v[0] = C::B;
+    const Fe<Fp> b = fe_to_mont<Fp>(braw), one = fe_one<Fp>();
+    for (;;) {
+        // x-search first, for every lane of the wave, and only then the (much longer) cofactor multiplication: with the
+        // multiplication inside the search loop a wave would run it once per iteration in which ANY lane succeeds.
+        Aff<C> cand;
+        for (;;) {
+            Fe<Fp> rhs = fe_add(fe_mul(fe_sqr(x), x), b);
+            Fe<Fp> s = fe_pow_words<Fp>(rhs, e);
+            bool found = !fe_is_zero(rhs) && fe_eq(fe_sqr(s), rhs);
+            cand.x = x;
+            cand.y = s;
+            x = fe_add(x, one);
+            if (found) break;
+        }
+        uint32_t sw[Fp::NW];
+        fe_pack_words<Fp>(sw, fe_from_mont<Fp>(cand.y));
+        if (sw[0] & 1) cand.y = fe_neg(cand.y);
+        if (C::COFACTOR_IS_ONE) return cand;
+        const uint32_t cof[8] = {C::COFACTOR[0], C::COFACTOR[1], C::COFACTOR[2], C::COFACTOR[3], 0, 0, 0, 0};
+        Aff<C> r = xyzz_to_aff<C>(xyzz_mul_words<C>(cof, cand));
+        if (!aff_is_inf(r)) return r;   // h * P == O cannot happen for a point of the curve group unless P is in the h-torsion
+    }
+}
+
+// out[i] = from_msg_hash(message i).  offs == nullptr: message i = prefix || decimal(first + i) (get_generators);
+// otherwise message i = bytes[offs[i] .. offs[i+1]).
+template <class C>
+__global__ void __launch_bounds__(kHashBlock, 2) k_hash_to_g1(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs, uint32_t prefix_len,
+                                                           uint64_t first, size_t n, SqrtExp e, AffPacked<C>* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    HashMsg m;
+    m.tail_len = 0;
+    if (offs) {
+        m.head = bytes + offs[i];
+        m.head_len = (uint32_t)(offs[i + 1] - offs[i]);
+    } else {
+        m.head = bytes;
+        m.head_len = prefix_len;
+        uint64_t v = first + i;
+        uint8_t rev[20];
+        uint32_t nd = 0;
+        do { rev[nd++] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
+        for (uint32_t k = 0; k < nd; k++) m.tail[k] = rev[nd - 1 - k];
+        m.tail_len = nd;
+    }
+    out[i] = aff_pack(hash_to_g1<C>(m, e));
+}
+
+}  // namespace bp

@@ -96,6 +96,16 @@ int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out
 /* out[i] = k[i] * G.  Batched form of `&G1::generator() * &FieldElement` (src/utils/mod.rs:34); used to build
  * synthetic generator vectors on the device. */
 int bp_g1vec_fixed_base_mul(bp_ctx* ctx, const bp_frvec* k, bp_g1vec** out);
+/* Hash to G1, batched: out[i] = `G1::from_msg_hash(message i)` (amcl_wrapper; the reference calls it at
+ * src/utils/mod.rs:20 and for the `g`, `h` of every gadget test, e.g. src/r1cs/gadgets/bound_check.rs:202-203).
+ * Message i = msgs[offsets[i] .. offsets[i+1]); offsets has n + 1 entries, offsets[0] == 0.
+ * Map (restated from amcl's published `ECP::mapit`, see bp_hash.cuh): x = BE(SHAKE256(msg)[0..MODBYTES)) mod p,
+ * try-and-increment on x, the even square root, multiplication by the cofactor. */
+int bp_g1vec_from_msg_hash(bp_ctx* ctx, const uint8_t* msgs, const uint64_t* offsets, size_t n, bp_g1vec** out);
+/* `get_generators(prefix, n)` (src/utils/mod.rs:16-23): out[i] = from_msg_hash(prefix || decimal(first + i)), i < n.
+ * The reference counts from 1 (first = 1); `first` lets ranks generate disjoint index ranges.  The messages are built
+ * on the device: nothing but the prefix crosses PCIe. */
+int bp_get_generators(bp_ctx* ctx, const uint8_t* prefix, size_t prefix_len, uint64_t first, size_t n, bp_g1vec** out);
 /* out[i] = k[i] * p[i]   (`&G1 * &FieldElement`, src/r1cs/prover.rs:358,423,550), batched. */
 int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1vec** out);
 

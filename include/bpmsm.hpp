@@ -121,6 +121,21 @@ public:
         check(bp_g1vec_fixed_base_mul(ctx.handle(), k.handle(), &h), "bp_g1vec_fixed_base_mul");
         return G1Vector(ctx, h);
     }
+    // utils::get_generators(prefix, n) (src/utils/mod.rs:16-23): from_msg_hash(prefix || decimal(i)), i = 1..n
+    static G1Vector get_generators(Context& ctx, const std::string& prefix, size_t n) {
+        bp_g1vec* h = nullptr;
+        check(bp_get_generators(ctx.handle(), reinterpret_cast<const uint8_t*>(prefix.data()), prefix.size(), 1, n, &h), "bp_get_generators");
+        return G1Vector(ctx, h);
+    }
+    // [G1::from_msg_hash(m) for m in messages]
+    static G1Vector from_msg_hash(Context& ctx, const std::vector<std::string>& messages) {
+        std::vector<uint64_t> offs(messages.size() + 1, 0);
+        std::string all;
+        for (size_t i = 0; i < messages.size(); i++) { all += messages[i]; offs[i + 1] = all.size(); }
+        bp_g1vec* h = nullptr;
+        check(bp_g1vec_from_msg_hash(ctx.handle(), reinterpret_cast<const uint8_t*>(all.data()), offs.data(), messages.size(), &h), "bp_g1vec_from_msg_hash");
+        return G1Vector(ctx, h);
+    }
     size_t len() const { return bp_g1vec_len(h_); }
     Bytes to_bytes() const {
         Bytes out(len() * ctx_->point_bytes());

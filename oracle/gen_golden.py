@@ -227,10 +227,33 @@ def gen_ipp():
     return out
 
 
+def gen_hash_to_g1():
+    """G1::from_msg_hash / get_generators (src/utils/mod.rs:16-23) restated in pyref.g1_from_msg_hash; SHAKE256 digests are
+    cross-checked against hashlib here so that at least the hash half is pinned by an independent implementation."""
+    import hashlib
+    msgs = [b"", b"g", b"h", b"G1", b"H1", b"G4096", b"bulletproofs", b"a" * 135, b"b" * 136, b"c" * 137, b"d" * 300]
+    out = {"shake256": [], "curves": {}}
+    for m in msgs:
+        d = R.shake256(m, 48)
+        assert d == hashlib.shake_256(m).digest(48)
+        out["shake256"].append({"msg": h(m), "digest48": h(d)})
+    for c in (R.BLS12_381, R.BN254):
+        pts = []
+        for m in msgs:
+            P = R.g1_from_msg_hash(c, m)
+            assert c.on_curve(P) and c.mul_raw(c.r, P) is None
+            pts.append({"msg": h(m), "point": pt_le(c, P)})
+        gens = {}
+        for prefix, n in (("G", 12), ("H", 12), ("x" * 131, 3)):
+            gens[prefix] = [pt_le(c, P) for P in R.get_generators(c, prefix, n)]
+        out["curves"][c.name] = {"from_msg_hash": pts, "get_generators": gens}
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("curves", gen_curves), ("field", gen_field), ("g1", gen_g1), ("merlin", gen_merlin),
-                     ("msm", gen_msm), ("ipp", gen_ipp)):
+                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1)):
         print("generating", name, file=sys.stderr)
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=0, sort_keys=True)

@@ -3,6 +3,7 @@
 #include "oracle.h"
 #include "orc_merlin.h"
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -41,6 +42,7 @@
 #define FP_LE_BYTES 48
 #define FR_LE_BYTES 32
 #define MODBYTES 48
+#define COFACTOR_WORDS {0x8c00aaab0000aaabULL, 0x396c8c005555e156ULL, 0, 0}   /* (x-1)^2/3 */
 #include "orc_curve_tmpl.h"
 #include "orc_ipp_tmpl.h"
 #include "orc_api_tmpl.h"
@@ -52,6 +54,7 @@
 #undef FP_LE_BYTES
 #undef FR_LE_BYTES
 #undef MODBYTES
+#undef COFACTOR_WORDS
 
 #define C(x) bn254_##x
 #define FP(x) fp254_##x
@@ -61,6 +64,7 @@
 #define FP_LE_BYTES 32
 #define FR_LE_BYTES 32
 #define MODBYTES 32
+#define COFACTOR_WORDS {1, 0, 0, 0}
 #include "orc_curve_tmpl.h"
 #include "orc_ipp_tmpl.h"
 #include "orc_api_tmpl.h"
@@ -72,6 +76,7 @@
 #undef FP_LE_BYTES
 #undef FR_LE_BYTES
 #undef MODBYTES
+#undef COFACTOR_WORDS
 
 /* ---------------- constants (public parameters; checked against tests/golden/curves.json) ------------- */
 static void hex_to_words(uint64_t* out, int nwords, const char* hex) {
@@ -129,6 +134,12 @@ int orc_g1_to_amcl(int curve, const uint8_t* p, uint8_t* out) {
     if (curve == 0) { bls381_aff_t a; bls381_aff_from_le(&a, p); bls381_aff_to_amcl(out, &a, 48); return 0; }
     if (curve == 1) { bn254_aff_t a; bn254_aff_from_le(&a, p); bn254_aff_to_amcl(out, &a, 32); return 0; }
     return 2;
+}
+int orc_g1_from_msg_hash(int curve, const uint8_t* msg, size_t len, uint8_t* out) {
+    DISPATCH(bls381_api_from_msg_hash(msg, len, out), bn254_api_from_msg_hash(msg, len, out));
+}
+int orc_get_generators(int curve, const uint8_t* prefix, size_t prefix_len, uint64_t first, size_t n, int nthreads, uint8_t* out) {
+    DISPATCH(bls381_api_get_generators(prefix, prefix_len, first, n, nthreads, out), bn254_api_get_generators(prefix, prefix_len, first, n, nthreads, out));
 }
 int orc_msm(int curve, int algo, const uint8_t* points, const uint8_t* scalars, size_t n, int nthreads, uint8_t* out) {
     DISPATCH(bls381_api_msm(algo, points, scalars, n, nthreads, out), bn254_api_msm(algo, points, scalars, n, nthreads, out));

@@ -33,6 +33,9 @@ int orc_g1_add(int curve, const uint8_t* p, const uint8_t* q, uint8_t* out);
 int orc_g1_mul(int curve, const uint8_t* k, const uint8_t* p, uint8_t* out);
 int orc_g1_binary_scalar_mul(int curve, const uint8_t* p, const uint8_t* h, const uint8_t* r1, const uint8_t* r2, uint8_t* out);
 int orc_g1_fixed_base_batch(int curve, const uint8_t* ks, size_t n, int nthreads, uint8_t* out_points);
+/* G1::from_msg_hash (amcl_wrapper) and get_generators (src/utils/mod.rs:16-23): msg -> point, x || y little-endian */
+int orc_g1_from_msg_hash(int curve, const uint8_t* msg, size_t len, uint8_t* out);
+int orc_get_generators(int curve, const uint8_t* prefix, size_t prefix_len, uint64_t first, size_t n, int nthreads, uint8_t* out);
 int orc_g1_to_amcl(int curve, const uint8_t* p, uint8_t* out /* 2*modbytes+1 */);
 
 /* algo: 0 naive, 1 Strauss wNAF-5 single thread (reference-like), 2 Pippenger with nthreads */

@@ -194,6 +194,68 @@ static int C(api_commit_point)(orc_transcript* tr, const char* label, const uint
     C(aff_t) a; C(aff_from_le)(&a, p); C(t_commit_point)(tr, label, &a); return 0;
 }
 
+/* ---- hash to G1 ---------------------------------------------------------------------------------------------
+ * amcl_wrapper `G1::from_msg_hash(msg)` = `GroupG1::mapit(&hash_msg(msg))`, the call behind get_generators
+ * (src/utils/mod.rs:16-23).  [UNVERIFIED-RECALL] of amcl `ECP::mapit` / `new_bigint(x, 0)` / `cfp` (crate not vendored):
+ * x = BE(SHAKE256(msg)[0..MODBYTES]) mod p; try-and-increment on x; y = the even square root; multiply by the cofactor. */
+static const uint64_t C(COF)[FR_NL] = COFACTOR_WORDS;
+static void C(from_msg_hash)(C(aff_t)* out, const uint8_t* msg, size_t len) {
+    uint8_t h[MODBYTES];
+    orc_shake256(msg, len, h, MODBYTES);
+    FP(t) x, one; FP(from_be_reduce)(&x, h, MODBYTES);
+    memcpy(one.l, FP(P).one, sizeof one.l);
+    uint64_t e[FP_NL];                                   /* (p + 1) / 4; p = 3 mod 4 for both curves */
+    memcpy(e, FP(P).mod, sizeof e);
+    for (int i = 0; i < FP_NL; i++) { if (++e[i]) break; }
+    for (int i = 0; i < FP_NL; i++) e[i] = (e[i] >> 2) | (i + 1 < FP_NL ? e[i + 1] << 62 : 0);
+    for (;;) {
+        FP(t) rhs, s, s2;
+        FP(sqr)(&rhs, &x); FP(mul)(&rhs, &rhs, &x); FP(add)(&rhs, &rhs, &C(B));
+        FP(pow)(&s, &rhs, e); FP(sqr)(&s2, &s);
+        int ok = !FP(is_zero)(&rhs) && FP(eq)(&s2, &rhs);
+        C(aff_t) cand; cand.inf = 0; cand.x = x;
+        FP(add)(&x, &x, &one);
+        if (!ok) continue;
+        uint64_t raw[FP_NL]; FP(to_raw)(raw, &s);
+        if (raw[0] & 1) FP(neg)(&s, &s);
+        cand.y = s;
+        C(jac_t) j; C(jac_mul_raw)(&j, C(COF), &cand);
+        if (C(jac_is_inf)(&j)) continue;
+        C(jac_to_aff)(out, &j);
+        return;
+    }
+}
+static int C(api_from_msg_hash)(const uint8_t* msg, size_t len, uint8_t* out) {
+    C(aff_t) r; C(from_msg_hash)(&r, msg, len); C(aff_to_le)(out, &r); return 0;
+}
+/* out[i] = from_msg_hash(prefix || decimal(first + i)), i < n  (get_generators uses first = 1) */
+typedef struct { const uint8_t* prefix; size_t plen; uint64_t first; size_t lo, hi; uint8_t* out; } C(gg_job_t);
+static void* C(gg_worker)(void* arg) {
+    C(gg_job_t)* jb = (C(gg_job_t)*)arg;
+    uint8_t* buf = (uint8_t*)malloc(jb->plen + 24);
+    memcpy(buf, jb->prefix, jb->plen);
+    for (size_t i = jb->lo; i < jb->hi; i++) {
+        int nd = snprintf((char*)buf + jb->plen, 24, "%llu", (unsigned long long)(jb->first + i));
+        C(aff_t) r; C(from_msg_hash)(&r, buf, jb->plen + (size_t)nd);
+        C(aff_to_le)(jb->out + i * 2 * FP_LE_BYTES, &r);
+    }
+    free(buf);
+    return NULL;
+}
+static int C(api_get_generators)(const uint8_t* prefix, size_t plen, uint64_t first, size_t n, int nthreads, uint8_t* out) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+    C(gg_job_t)* jobs = (C(gg_job_t)*)malloc(sizeof(C(gg_job_t)) * nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (C(gg_job_t)){prefix, plen, first, n * t / nthreads, n * (t + 1) / nthreads, out};
+        pthread_create(&th[t], NULL, C(gg_worker), &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+    return 0;
+}
+
 static void C(api_init)(const uint64_t* p, const uint64_t* r, uint64_t b, const uint64_t* gx, const uint64_t* gy) {
     FP(init)(p); FR(init)(r);
     FP(from_u64)(&C(B), b);

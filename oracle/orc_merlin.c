@@ -31,6 +31,17 @@ void orc_keccak_f1600(uint8_t st[200]) {
     for (int i = 0; i < 25; i++) for (int j = 0; j < 8; j++) st[8 * i + j] = (uint8_t)(a[i] >> (8 * j));
 }
 
+void orc_shake256(const uint8_t* msg, size_t len, uint8_t* out, size_t out_len) {
+    enum { RATE = 136 };
+    uint8_t st[200] = {0};
+    size_t pos = 0;
+    for (size_t i = 0; i < len; i++) { st[pos++] ^= msg[i]; if (pos == RATE) { orc_keccak_f1600(st); pos = 0; } }
+    st[pos] ^= 0x1f; st[RATE - 1] ^= 0x80;
+    orc_keccak_f1600(st);
+    pos = 0;
+    for (size_t i = 0; i < out_len; i++) { if (pos == RATE) { orc_keccak_f1600(st); pos = 0; } out[i] = st[pos++]; }
+}
+
 enum { STROBE_R = 166, FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, FLAG_K = 32 };
 
 static void run_f(orc_transcript* t) {

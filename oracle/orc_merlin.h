@@ -17,6 +17,8 @@ typedef struct {
 } orc_transcript;
 
 void orc_keccak_f1600(uint8_t st[200]);
+/* FIPS 202 SHAKE256 (rate 136, suffix 0x1f) -- amcl_wrapper `hash_msg` uses it for G1::from_msg_hash */
+void orc_shake256(const uint8_t* msg, size_t len, uint8_t* out, size_t out_len);
 void orc_transcript_init(orc_transcript* t, const uint8_t* label, size_t label_len);
 void orc_transcript_append(orc_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
 void orc_transcript_append_u64(orc_transcript* t, const uint8_t* label, size_t label_len, uint64_t x);

@@ -19,6 +19,10 @@ this file instead:
       src/ipp.rs:35-202  (create_ipp), :204-260 (verify_ipp), :262-315 (verification_scalars),
       src/transcript.rs:29-61 (labels / domain separators),
       src/utils/mod.rs:16-23 (get_generators naming).
+  * hash-to-G1 (`g1_from_msg_hash`): SHAKE256 is checked against hashlib; the map itself (amcl `ECP::mapit`:
+    try-and-increment on x, even y, cofactor multiplication) is restated from memory of amcl's published sources
+    [UNVERIFIED-RECALL] -- outputs are on the curve and in the r-torsion by construction, but equality with the
+    reference's generators cannot be checked here.
 """
 
 # --------------------------------------------------------------------------- curves
@@ -62,6 +66,15 @@ class Curve:
         x3 = (lam * lam - x1 - x2) % p
         y3 = (lam * (x1 - x3) - y1) % p
         return (x3, y3)
+
+    def mul_raw(self, k, P):
+        R = None
+        while k:
+            if k & 1:
+                R = self.add(R, P)
+            P = self.add(P, P)
+            k >>= 1
+        return R
 
     def mul(self, k, P):
         k %= self.r
@@ -127,6 +140,9 @@ BN254 = Curve(
     modbytes=32,
 )
 
+BLS12_381.cofactor = 0x396C8C005555E1568C00AAAB0000AAAB   # (x-1)^2/3, amcl rom CURVE_COF
+BN254.cofactor = 1
+
 CURVES = {c.name: c for c in (BLS12_381, BN254)}
 
 # --------------------------------------------------------------------------- Keccak / STROBE / Merlin
@@ -163,6 +179,56 @@ def keccak_f1600(state: bytearray):
     for x in range(5):
         for y in range(5):
             state[8 * (x + 5 * y): 8 * (x + 5 * y) + 8] = A[x][y].to_bytes(8, "little")
+
+
+def shake256(msg: bytes, outlen: int) -> bytes:
+    """FIPS 202 SHAKE256 on the Keccak-f above (rate 136, suffix 0x1f)."""
+    rate = 136
+    st = bytearray(200)
+    buf = bytearray(msg) + b"\x1f"
+    buf += b"\x00" * ((-len(buf)) % rate)
+    buf[-1] |= 0x80
+    for off in range(0, len(buf), rate):
+        for i in range(rate):
+            st[i] ^= buf[off + i]
+        keccak_f1600(st)
+    out = bytearray()
+    while len(out) < outlen:
+        out += st[:rate]
+        if len(out) < outlen:
+            keccak_f1600(st)
+    return bytes(out[:outlen])
+
+
+def g1_from_msg_hash(curve, msg: bytes):
+    """amcl_wrapper `G1::from_msg_hash(msg)` = `GroupG1::mapit(&hash_msg(msg))`, the call behind
+    `get_generators` (src/utils/mod.rs:16-23) and the gadget tests' `g`, `h` (e.g. src/r1cs/gadgets/bound_check.rs:200-203).
+    [UNVERIFIED-RECALL] of amcl_wrapper 0.1.x `utils::hash_msg` and amcl `ECP::mapit` / `ECP::new_bigint(x, 0)` / `cfp`:
+      h  = SHAKE256(msg)[0..MODBYTES];  x = BE(h) mod p
+      loop: rhs = x^3 + b; if rhs is a non-zero square: y = sqrt(rhs) with even canonical value, P = (x, y)
+            x += 1 (always, as amcl does);  if P found: P = cofactor * P; if P != O: return P
+    """
+    p = curve.p
+    x = int.from_bytes(shake256(msg, curve.modbytes), "big") % p
+    while True:
+        rhs = (x * x * x + curve.b) % p
+        P = None
+        if rhs != 0 and pow(rhs, (p - 1) // 2, p) == 1:
+            y = pow(rhs, (p + 1) // 4, p)     # p = 3 mod 4 for both curves
+            if y & 1:
+                y = p - y
+            P = (x, y)
+        x = (x + 1) % p
+        if P is None:
+            continue
+        P = curve.mul_raw(curve.cofactor, P)
+        if P is not None:
+            return P
+
+
+def get_generators(curve, prefix: str, n: int):
+    """src/utils/mod.rs:16-23: G1::from_msg_hash(prefix || decimal(i)) for i = 1..n."""
+    return [g1_from_msg_hash(curve, (prefix + str(i)).encode()) for i in range(1, n + 1)]
 
 
 class Strobe128:

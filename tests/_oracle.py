@@ -176,3 +176,24 @@ def ipp_verification_scalars(curve, tr, L, R, lg_n, n):
     if rc:
         return rc, None
     return 0, (us.raw[: lg_n * 32], uis.raw[: lg_n * 32], s.raw[: n * 32])
+
+
+def g1_from_msg_hash(curve, msg):
+    out = _buf(pt_bytes(curve))
+    assert lib().orc_g1_from_msg_hash(curve, bytes(msg), ctypes.c_size_t(len(msg)), out) == 0
+    return out.raw
+
+
+def get_generators(curve, prefix, n, first=1, nthreads=1):
+    """src/utils/mod.rs:16-23: from_msg_hash(prefix || decimal(i)), i = first .. first + n - 1."""
+    prefix = prefix.encode() if isinstance(prefix, str) else bytes(prefix)
+    out = _buf(pt_bytes(curve) * max(n, 1))
+    assert lib().orc_get_generators(curve, prefix, ctypes.c_size_t(len(prefix)), ctypes.c_uint64(first), ctypes.c_size_t(n),
+                                    nthreads, out) == 0
+    return out.raw[: pt_bytes(curve) * n]
+
+
+def group_order(curve):
+    """r of the curve (public constant)."""
+    return (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001 if curve == 0
+            else 0x2523648240000001BA344D8000000007FF9F800000000010A10000000000000D)

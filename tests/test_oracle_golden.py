@@ -144,3 +144,42 @@ def test_random_scalars_match_pyref(golden):
         rng = pyref.SplitMix64(77)
         exp = b"".join(c.fr_to_le(rng.scalar(c)) for _ in range(20))
         assert O.random_scalars(c.curve_id, 77, 20) == exp
+
+
+def test_shake256_matches_hashlib_and_golden(golden):
+    """The hash half of G1::from_msg_hash is pinned by an independent implementation (hashlib's SHAKE256)."""
+    import ctypes
+    import hashlib
+    L = O.lib()
+    for c in golden("hash_to_g1")["shake256"]:
+        msg = bytes.fromhex(c["msg"])
+        out = ctypes.create_string_buffer(48)
+        L.orc_shake256(msg, ctypes.c_size_t(len(msg)), out, ctypes.c_size_t(48))
+        assert out.raw.hex() == c["digest48"] == hashlib.shake_256(msg).hexdigest(48)
+    for n in (0, 1, 135, 136, 137, 271, 272, 273, 1000):
+        msg = bytes((7 * i + n) & 0xFF for i in range(n))
+        out = ctypes.create_string_buffer(200)
+        L.orc_shake256(msg, ctypes.c_size_t(n), out, ctypes.c_size_t(200))   # squeeze past one rate block
+        assert out.raw == hashlib.shake_256(msg).digest(200)
+
+
+@pytest.mark.parametrize("name", ["bls12_381", "bn254"])
+def test_hash_to_g1_golden(golden, name):
+    """C oracle vs the Python-int restatement of amcl's mapit (tests/golden/hash_to_g1.json); outputs lie on the curve."""
+    cid = O.CURVE_IDS[name]
+    g = golden("hash_to_g1")["curves"][name]
+    for c in g["from_msg_hash"]:
+        p = O.g1_from_msg_hash(cid, bytes.fromhex(c["msg"]))
+        assert p.hex() == c["point"]
+        assert O.on_curve(cid, p)
+    for prefix, pts in g["get_generators"].items():
+        got = O.get_generators(cid, prefix, len(pts), nthreads=3)
+        assert got.hex() == "".join(pts)
+    # a shifted counter continues the same sequence
+    pts = g["get_generators"]["G"]
+    assert O.get_generators(cid, "G", 4, first=5).hex() == "".join(pts[4:8])
+    # r * P == O: the cofactor was cleared
+    r = int(golden("curves")[name]["r"], 16)
+    p = bytes.fromhex(pts[0])
+    rm1 = O.g1_mul(cid, (r - 1).to_bytes(32, "little"), p)
+    assert O.g1_add(cid, rm1, p) == bytes(len(p))
