@@ -35,17 +35,21 @@ def best_of(fn, reps=5):
 
 
 def gens(ctx, n, seed):
+    """Points with KNOWN discrete logs k_i (k_i * G), for the MSM legs that are verified by linearity."""
     info = bp.curve_info(ctx.curve)
     k = random_scalars(ctx.r, info.fr_bits, n, seed)
     return bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, k, n)), k
 
 
+def hashed_gens(ctx, prefix, n):
+    """The reference's own construction: utils::get_generators(prefix, n) (src/utils/mod.rs:16-23), on the device."""
+    return bp.get_generators(ctx, prefix, n)
+
+
 def ipp_instance(ctx, n, seed):
     info = bp.curve_info(ctx.curve)
-    Gv, _ = gens(ctx, n, seed)
-    Hv, _ = gens(ctx, n, seed + 1)
-    Qv, _ = gens(ctx, 1, seed + 2)
-    Q = Qv.to_bytes()
+    Gv, Hv = hashed_gens(ctx, "g", n), hashed_gens(ctx, "h", n)          # src/ipp.rs:340-341
+    Q = bp.G1Vector.from_msg_hash(ctx, [b"Q"]).to_bytes()                 # :342
     a = bp.FieldElementVector.from_bytes(ctx, random_scalars(ctx.r, info.fr_bits, n, seed + 3), n)
     b = bp.FieldElementVector.from_bytes(ctx, random_scalars(ctx.r, info.fr_bits, n, seed + 4), n)
     Gf = bp.FieldElementVector.from_ints(ctx, [1] * n)                                     # as in src/ipp.rs:344
@@ -127,7 +131,33 @@ def cfg5():
     return {"config": "cfg5: BN254 (AMCL/Nogami) 2^20 MSM + IPP n=2^12", "msm_ms": t * 1e3, "msm_scalar_muls_per_s": n / t, "msm_ok": bool(got == want), "ipp": ipp}
 
 
+def generators():
+    """get_generators("G", n) -- SURVEY 8f-1; the reference calls generator creation "very slow"
+    (src/r1cs/gadgets/sparse_merkle_tree_8_ary.rs:255).  CPU figure = the C oracle on a bounded sample."""
+    out = {"config": "generators: utils::get_generators(\"G\", n) = n x G1::from_msg_hash on the device"}
+    ncpu = os.cpu_count() or 1
+    for cname, cid in bp.CURVE_IDS.items():
+        ctx = bp.Context(cid, 0)
+        bp.get_generators(ctx, "warm", 256)
+        sample = 1024
+        t0 = time.perf_counter()
+        ref = O.get_generators(cid, "G", sample, nthreads=1)
+        cpu1 = (time.perf_counter() - t0) / sample
+        t0 = time.perf_counter()
+        O.get_generators(cid, "G", sample * 16, nthreads=ncpu)
+        cpun = (time.perf_counter() - t0) / (sample * 16)
+        res = {"cpu_oracle_points_per_s_1_thread": 1 / cpu1, "cpu_oracle_points_per_s_all_threads": 1 / cpun, "cpu_threads": ncpu}
+        for lg in (12, 16, 20):
+            n = 1 << lg
+            t, v = best_of(lambda: bp.get_generators(ctx, "G", n), reps=3)
+            res["n=2^%d" % lg] = {"ms": t * 1e3, "points_per_s": n / t, "first_%d_match_oracle" % sample: bool(v.to_bytes(0, sample) == ref)}
+            v.free()
+        out[cname] = res
+        ctx.close()
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg5"]
+    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg5", "generators"]
     for name in which:
         print(json.dumps({name: globals()[name]()}), flush=True)

@@ -22,13 +22,23 @@ template <class C> SqrtExp sqrt_exponent() {   // (p + 1) / 4 from the modulus w
 }
 
 template <class C>
-int launch_hash(bp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offs, uint32_t prefix_len, uint64_t first, size_t n, void* out) {
+int launch_hash(bp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offs, uint32_t prefix_len, uint64_t first, size_t n,
+                unsigned long long* d_next, void* out) {
     static_assert((C::Fp::Words::MODW[0] & 3) == 3, "sqrt by (p+1)/4 needs p = 3 mod 4");
-    unsigned grid = (unsigned)((n + kHashBlock - 1) / kHashBlock);
-    hipLaunchKernelGGL(k_hash_to_g1<C>, dim3(grid), dim3(kHashBlock), 0, ctx->stream, d_bytes, d_offs, prefix_len, first, n, sqrt_exponent<C>(),
+    const SqrtExp e = sqrt_exponent<C>();
+    // search: at most two resident blocks per CU's worth of lanes; each lane pulls messages until the counter passes n
+    size_t want = (n + kHashBlock - 1) / kHashBlock;
+    unsigned grid = (unsigned)(want < 512 ? want : 512);
+    HIPCHK(hipMemsetAsync(d_next, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_hash_search<C>, dim3(grid), dim3(kHashBlock), 0, ctx->stream, d_bytes, d_offs, prefix_len, first, n, e, d_next,
                        (AffPacked<C>*)out);
     HIPCHK(hipGetLastError());
-    BP_TRACE_SYNC(ctx, "k_hash_to_g1<C>");
+    BP_TRACE_SYNC(ctx, "k_hash_search<C>");
+    if (!C::COFACTOR_IS_ONE) {
+        hipLaunchKernelGGL(k_clear_cofactor<C>, dim3((unsigned)want), dim3(kHashBlock), 0, ctx->stream, n, e, (AffPacked<C>*)out);
+        HIPCHK(hipGetLastError());
+        BP_TRACE_SYNC(ctx, "k_clear_cofactor<C>");
+    }
     return BP_OK;
 }
 
@@ -37,19 +47,21 @@ int hash_common(bp_ctx* ctx, const uint8_t* bytes, size_t nbytes, const uint64_t
     int rc = bp_g1vec_alloc(ctx, n, out);
     if (rc) return rc;
     if (n == 0) return BP_OK;
-    void *d_bytes = nullptr, *d_offs = nullptr;
-    auto fail = [&](int code) { if (d_bytes) (void)hipFree(d_bytes); if (d_offs) (void)hipFree(d_offs); bp_g1vec_free(*out); *out = nullptr; return code; };
-    if (hipMalloc(&d_bytes, nbytes ? nbytes : 1) != hipSuccess) return fail(BP_ERR_DEVICE);
+    // staging: [next-message counter (8 B) | message bytes]; offsets separately (8-byte aligned)
+    void *d_stage = nullptr, *d_offs = nullptr;
+    auto fail = [&](int code) { if (d_stage) (void)hipFree(d_stage); if (d_offs) (void)hipFree(d_offs); bp_g1vec_free(*out); *out = nullptr; return code; };
+    if (hipMalloc(&d_stage, 8 + (nbytes ? nbytes : 1)) != hipSuccess) return fail(BP_ERR_DEVICE);
+    uint8_t* d_bytes = (uint8_t*)d_stage + 8;
     if (nbytes && hipMemcpyAsync(d_bytes, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(BP_ERR_DEVICE);
     if (offs) {
         if (hipMalloc(&d_offs, (n + 1) * sizeof(uint64_t)) != hipSuccess) return fail(BP_ERR_DEVICE);
         if (hipMemcpyAsync(d_offs, offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(BP_ERR_DEVICE);
     }
-    if (ctx->curve == BP_CURVE_BLS12_381) rc = launch_hash<Bls381>(ctx, (const uint8_t*)d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (*out)->d);
-    else rc = launch_hash<Bn254>(ctx, (const uint8_t*)d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (*out)->d);
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = launch_hash<Bls381>(ctx, d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (unsigned long long*)d_stage, (*out)->d);
+    else rc = launch_hash<Bn254>(ctx, d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (unsigned long long*)d_stage, (*out)->d);
     if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_DEVICE;
     if (rc) return fail(rc);
-    (void)hipFree(d_bytes);
+    (void)hipFree(d_stage);
     if (d_offs) (void)hipFree(d_offs);
     return BP_OK;
 }

@@ -113,7 +113,8 @@ template <class P> __device__ __noinline__ Fe<P> fe_pow_words(const Fe<P>& a, co
     return acc;
 }
 
-template <class C> __device__ Aff<C> hash_to_g1(const HashMsg& m, const SqrtExp& e) {
+// x = BE(SHAKE256(msg)[0 .. MODBYTES)) mod p, Montgomery form
+template <class C> __device__ Fe<typename C::Fp> hash_to_x(const HashMsg& m) {
     using Fp = typename C::Fp;
     uint64_t lanes[8];
     shake256_dev(m, lanes);
@@ -127,40 +128,29 @@ template <class C> __device__ Aff<C> hash_to_g1(const HashMsg& m, const SqrtExp&
         xw[2 * l + 1] = (uint32_t)(v >> 32);
     }
     // x < 2^(8 MODBYTES) < R: the Montgomery product with R^2 mod p reduces it (pre-subtraction value < p + p/64)
-    Fe<Fp> x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
-    Fe<Fp> braw = fe_zero<Fp>();
-    braw.v[0] = C::B;
-    const Fe<Fp> b = fe_to_mont<Fp>(braw), one = fe_one<Fp>();
-    for (;;) {
-        // x-search first, for every lane of the wave, and only then the (much longer) cofactor multiplication: with the
-        // multiplication inside the search loop a wave would run it once per iteration in which ANY lane succeeds.
-        Aff<C> cand;
-        for (;;) {
-            Fe<Fp> rhs = fe_add(fe_mul(fe_sqr(x), x), b);
-            Fe<Fp> s = fe_pow_words<Fp>(rhs, e);
-            bool found = !fe_is_zero(rhs) && fe_eq(fe_sqr(s), rhs);
-            cand.x = x;
-            cand.y = s;
-            x = fe_add(x, one);
-            if (found) break;
-        }
-        uint32_t sw[Fp::NW];
-        fe_pack_words<Fp>(sw, fe_from_mont<Fp>(cand.y));
-        if (sw[0] & 1) cand.y = fe_neg(cand.y);
-        if (C::COFACTOR_IS_ONE) return cand;
-        const uint32_t cof[8] = {C::COFACTOR[0], C::COFACTOR[1], C::COFACTOR[2], C::COFACTOR[3], 0, 0, 0, 0};
-        Aff<C> r = xyzz_to_aff<C>(xyzz_mul_words<C>(cof, cand));
-        if (!aff_is_inf(r)) return r;   // h * P == O cannot happen for a point of the curve group unless P is in the h-torsion
-    }
+    return fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
 }
 
-// out[i] = from_msg_hash(message i).  offs == nullptr: message i = prefix || decimal(first + i) (get_generators);
-// otherwise message i = bytes[offs[i] .. offs[i+1]).
-template <class C>
-__global__ void __launch_bounds__(kHashBlock, 2) k_hash_to_g1(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs, uint32_t prefix_len,
-                                                           uint64_t first, size_t n, SqrtExp e, AffPacked<C>* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// One try of amcl's `new_bigint(x, 0)`: is x^3 + b a non-zero square?  If so cand = (x, even root).  x is incremented
+// either way (mapit does `x.inc(1)` before looking at the result).
+template <class C> __device__ __forceinline__ bool try_x(Fe<typename C::Fp>& x, const SqrtExp& e, Aff<C>& cand) {
+    using Fp = typename C::Fp;
+    Fe<Fp> braw = fe_zero<Fp>();
+    braw.v[0] = C::B;
+    Fe<Fp> rhs = fe_add(fe_mul(fe_sqr(x), x), fe_to_mont<Fp>(braw));
+    Fe<Fp> s = fe_pow_words<Fp>(rhs, e);
+    bool found = !fe_is_zero(rhs) && fe_eq(fe_sqr(s), rhs);
+    cand.x = x;
+    x = fe_add(x, fe_one<Fp>());
+    if (found) {
+        uint32_t sw[Fp::NW];
+        fe_pack_words<Fp>(sw, fe_from_mont<Fp>(s));
+        cand.y = (sw[0] & 1) ? fe_neg(s) : s;
+    }
+    return found;
+}
+
+__device__ __forceinline__ HashMsg make_msg(const uint8_t* bytes, const uint64_t* offs, uint32_t prefix_len, uint64_t first, size_t i) {
     HashMsg m;
     m.tail_len = 0;
     if (offs) {
@@ -176,7 +166,52 @@ __global__ void __launch_bounds__(kHashBlock, 2) k_hash_to_g1(const uint8_t* __r
         for (uint32_t k = 0; k < nd; k++) m.tail[k] = rev[nd - 1 - k];
         m.tail_len = nd;
     }
-    out[i] = aff_pack(hash_to_g1<C>(m, e));
+    return m;
+}
+
+// Stage 1: the x-search.  The number of tries is geometric (p = 1/2), so a wave that maps lane -> message statically runs
+// as long as its unluckiest lane (~7 tries for 64 lanes against a mean of 2).  Lanes therefore PULL messages from an atomic
+// counter: a lane that has found its point takes the next message while its neighbours are still searching.  Every lane
+// leaves the loop once the counter passes n (each try succeeds with probability 1/2, so the loop terminates).
+// out[i] = (x, even y) on the curve, cofactor not yet cleared; message i as in k_hash_to_g1 below.
+template <class C>
+__global__ void __launch_bounds__(kHashBlock, 2) k_hash_search(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs, uint32_t prefix_len,
+                                                               uint64_t first, size_t n, SqrtExp e, unsigned long long* __restrict__ next,
+                                                               AffPacked<C>* __restrict__ out) {
+    using Fp = typename C::Fp;
+    bool have = false;
+    size_t i = 0;
+    Fe<Fp> x = fe_zero<Fp>();
+    for (;;) {
+        if (!have) {
+            i = (size_t)atomicAdd(next, 1ull);
+            if (i >= n) break;
+            x = hash_to_x<C>(make_msg(bytes, offs, prefix_len, first, i));
+            have = true;
+        }
+        Aff<C> cand;
+        if (try_x<C>(x, e, cand)) {
+            out[i] = aff_pack(cand);
+            have = false;
+        }
+    }
+}
+
+// Stage 2 (curves with a cofactor): P <- h * P, uniform work for every lane.  h * P == O would need P in the h-torsion
+// (probability ~ h / #E); amcl then goes on with the next x, and so does this loop.
+template <class C>
+__global__ void __launch_bounds__(kHashBlock, 2) k_clear_cofactor(size_t n, SqrtExp e, AffPacked<C>* __restrict__ pts) {
+    using Fp = typename C::Fp;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<C> cand = aff_unpack(pts[i]);
+    const uint32_t cof[8] = {C::COFACTOR[0], C::COFACTOR[1], C::COFACTOR[2], C::COFACTOR[3], 0, 0, 0, 0};
+    for (;;) {
+        Aff<C> r = xyzz_to_aff<C>(xyzz_mul_words<C>(cof, cand));
+        if (!aff_is_inf(r)) { pts[i] = aff_pack(r); return; }
+        Fe<Fp> x = fe_add(cand.x, fe_one<Fp>());
+        while (!try_x<C>(x, e, cand)) {}
+    }
 }
 
 }  // namespace bp

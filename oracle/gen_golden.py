@@ -194,13 +194,19 @@ def gen_ipp():
             ("test_ipp_non_power_of_2_n8", 8, [1, 2, 3, 4, 9, 0, 0, 0], [5, 6, 7, 8, 10, 0, 0, 0], True),  # :393-489
             ("random_n8_gfactors", 8, None, None, False),
             ("random_n16", 16, None, None, True),
+            # the same unit test with its own generator construction (src/ipp.rs:340-342): get_generators("g"/"h", n),
+            # Q = G1::from_msg_hash("Q") -- kept last so that the cases above keep their RNG stream
+            ("test_ipp_n4_hashed_generators", 4, [1, 2, 3, 4], [5, 6, 7, 8], True),
         ):
             if a is None:
                 a = [rng.scalar(c) for _ in range(n)]
                 b = [rng.scalar(c) for _ in range(n)]
-            G = [c.mul(rng.scalar(c), G0) for _ in range(n)]
-            H = [c.mul(rng.scalar(c), G0) for _ in range(n)]
-            Q = c.mul(rng.scalar(c), G0)
+            if name.endswith("hashed_generators"):
+                G, H, Q = R.get_generators(c, "g", n), R.get_generators(c, "h", n), R.g1_from_msg_hash(c, b"Q")
+            else:
+                G = [c.mul(rng.scalar(c), G0) for _ in range(n)]
+                H = [c.mul(rng.scalar(c), G0) for _ in range(n)]
+                Q = c.mul(rng.scalar(c), G0)
             y_inv = rng.scalar(c)
             Gf = [1] * n if unit_gf else [rng.scalar(c) for _ in range(n)]
             Hf = [pow(y_inv, i, c.r) for i in range(n)]                                # new_vandermonde_vector

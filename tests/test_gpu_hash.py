@@ -107,3 +107,28 @@ def test_argument_errors(bp, ctxs):
     offs = (ctypes.c_uint64 * 2)(1, 2)               # must start at 0
     assert L.bp_g1vec_from_msg_hash(ctx.h, b"ab", ctypes.cast(offs, ctypes.c_void_p), 1, ctypes.byref(h)) == bp.BP_ERR_ARG
     assert L.bp_get_generators(ctx.h, b"G", 1, ctypes.c_uint64(2**64 - 2), 5, ctypes.byref(h)) == bp.BP_ERR_ARG   # counter would wrap
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_reference_test_ipp_end_to_end(bp, ctxs, golden, name):
+    """The reference's `test_ipp` (src/ipp.rs:325-390) with every input built the way the test builds it -- on the device:
+    G = get_generators("g", 4), H = get_generators("h", 4), Q = G1::from_msg_hash("Q") -- then create_ipp / verify_ipp."""
+    ctx = ctxs[name]
+    c = [x for x in golden("ipp")[name] if x["name"] == "test_ipp_n4_hashed_generators"][0]
+    n = c["n"]
+    Gv, Hv = bp.get_generators(ctx, "g", n), bp.get_generators(ctx, "h", n)
+    Q = bp.G1Vector.from_msg_hash(ctx, [b"Q"]).to_bytes()
+    assert Gv.to_bytes().hex() == "".join(c["G"]) and Hv.to_bytes().hex() == "".join(c["H"]) and Q.hex() == c["Q"]
+    a = bp.FieldElementVector.from_ints(ctx, [1, 2, 3, 4])
+    b = bp.FieldElementVector.from_ints(ctx, [5, 6, 7, 8])
+    Gf = bp.FieldElementVector.from_ints(ctx, [1] * n)
+    Hf = bp.FieldElementVector.from_bytes(ctx, b"".join(bytes.fromhex(x) for x in c["H_factors"]), n)
+    proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert proof.L.hex() == "".join(c["L"]) and proof.R.hex() == "".join(c["R"])
+    assert proof.a.hex() == c["a_out"] and proof.b.hex() == c["b_out"]
+    # P = G^a * H^(b .* y^-i) * Q^<a,b>   (src/ipp.rs:353-372)
+    pts = bp.G1Vector.from_bytes(ctx, Gv.to_bytes() + Hv.to_bytes() + Q, 2 * n + 1)
+    sc = bp.FieldElementVector.from_bytes(ctx, a.to_bytes() + b.hadamard_product(Hf).to_bytes() + a.inner_product(b), 2 * n + 1)
+    P = pts.multi_scalar_mul_var_time(sc)
+    assert P.hex() == c["P"]
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
