@@ -157,7 +157,51 @@ def generators():
     return out
 
 
+def batch_verify():
+    """m proofs over the same generators: bp_ipp_verify_batch (one MSM) against m calls of bp_ipp_verify."""
+    out = {"config": "batch_verify: m IPP proofs, same generators, one random-linear-combination MSM vs m single verifications, BLS12-381"}
+    ctx = bp.Context(bp.BLS12_381, 0)
+    info = bp.curve_info(ctx.curve)
+    for n, m in ((64, 64), (4096, 64), (4096, 512)):
+        Gv, Hv = hashed_gens(ctx, "g", n), hashed_gens(ctx, "h", n)
+        Gf = bp.FieldElementVector.from_ints(ctx, [1] * n)
+        Hf = bp.FieldElementVector.new_vandermonde_vector(ctx, random_scalars(ctx.r, info.fr_bits, 1, 900), n)
+        base = []
+        for j in range(min(m, 8)):                     # 8 distinct proofs, cycled to m (the verifier does not care)
+            Q = bp.G1Vector.from_msg_hash(ctx, [b"Q%d" % j]).to_bytes()
+            a = bp.FieldElementVector.from_bytes(ctx, random_scalars(ctx.r, info.fr_bits, n, 910 + j), n)
+            b = bp.FieldElementVector.from_bytes(ctx, random_scalars(ctx.r, info.fr_bits, n, 930 + j), n)
+            pr = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+            pts = bp.G1Vector.from_bytes(ctx, Gv.to_bytes() + Hv.to_bytes() + Q, 2 * n + 1)
+            sc = bp.FieldElementVector.from_bytes(ctx, a.to_bytes() + b.hadamard_product(Hf).to_bytes() + a.inner_product(b), 2 * n + 1)
+            base.append((pts.multi_scalar_mul_var_time(sc), Q, pr))
+        items = [base[j % len(base)] for j in range(m)]
+
+        def single():
+            for P, Q, pr in items:
+                bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, pr.a, pr.b, pr.L, pr.R)
+
+        def batch():
+            bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, [(bp.Transcript(b"innerproduct"), P, Q, pr.a, pr.b, pr.L, pr.R) for P, Q, pr in items])
+
+        ts, _ = best_of(single, reps=3)
+        tb, _ = best_of(batch, reps=3)
+        # a tampered proof anywhere in the batch is rejected
+        P, Q, pr = items[m // 2]
+        bad = list(items)
+        bad[m // 2] = (P, Q, type(pr)(pr.L, pr.R, ((int.from_bytes(pr.a, "little") + 1) % ctx.r).to_bytes(32, "little"), pr.b, pr.lg_n))
+        rejected = False
+        try:
+            bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, [(bp.Transcript(b"innerproduct"), P, Q, p.a, p.b, p.L, p.R) for P, Q, p in bad])
+        except bp.VerificationError:
+            rejected = True
+        out["n=%d,m=%d" % (n, m)] = {"single_total_ms": ts * 1e3, "batch_ms": tb * 1e3, "proofs_per_s_single": m / ts, "proofs_per_s_batch": m / tb,
+                                     "tampered_batch_rejected": rejected}
+    ctx.close()
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg5", "generators"]
+    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg5", "generators", "batch_verify"]
     for name in which:
         print(json.dumps({name: globals()[name]()}), flush=True)

@@ -127,6 +127,7 @@ SYMBOLS = {
     "bp_ipp_state_free": (_I, [_P]),
     "bp_ipp_create": (_I, [_P, _P, _U8P, _P, _P, _P, _P, _P, _P, _U8P, _U8P, ctypes.POINTER(ctypes.c_size_t), _U8P, _U8P]),
     "bp_ipp_verify": (_I, [_P, _P, _SZ, _P, _P, _U8P, _U8P, _P, _P, _U8P, _U8P, _U8P, _U8P, _SZ]),
+    "bp_ipp_verify_batch": (_I, [_P, _SZ, _SZ, _P, _P, _P, _P, _P, _SZ, _U8P]),
     "bp_ipp_verification_scalars": (_I, [_I, _P, _U8P, _U8P, _SZ, _SZ, _U8P, _U8P, _U8P]),
 }
 
@@ -538,6 +539,12 @@ class IPPState:
             pass
 
 
+class _ProofRef(ctypes.Structure):
+    """struct bp_ipp_proof_ref (include/bpmsm.h)"""
+    _fields_ = [("transcript", ctypes.c_void_p), ("P_le", ctypes.c_void_p), ("Q_le", ctypes.c_void_p), ("a_le32", ctypes.c_void_p),
+                ("b_le32", ctypes.c_void_p), ("L_le", ctypes.c_void_p), ("R_le", ctypes.c_void_p)]
+
+
 class IPP:
     """IPP::create_ipp / verify_ipp / verification_scalars (src/ipp.rs:22-316)."""
 
@@ -560,6 +567,31 @@ class IPP:
         lg_n = len(L_le) // ctx.point_bytes
         _check(lib().bp_ipp_verify(ctx.h, transcript.h, n, G_factors.h, H_factors.h, bytes(P_le), bytes(Q_le), G.h, H.h, bytes(a_le32),
                                    bytes(b_le32), bytes(L_le), bytes(R_le), lg_n), "bp_ipp_verify")
+
+    @staticmethod
+    def verify_batch(ctx, n, G_factors, H_factors, G, H, proofs, weights=None):
+        """Accept m proofs over the same generators with ONE MSM (random linear combination, bp_ipp_verify_batch).
+        proofs: iterable of (transcript, P_le, Q_le, a_le32, b_le32, L_le, R_le).  weights: m 32-byte LE scalars; by default
+        128 fresh random bits each from os.urandom.  Raises VerificationError if the combination is not the identity."""
+        proofs = list(proofs)
+        m = len(proofs)
+        lg_n = max(0, n.bit_length() - 1)
+        arr = (_ProofRef * max(1, m))()
+        keep = []
+        for i, (tr, P, Q, a, b, L, R) in enumerate(proofs):
+            bufs = [ctypes.create_string_buffer(bytes(x), max(1, len(x))) for x in (P, Q, a, b, L, R)]
+            if len(L) != lg_n * ctx.point_bytes or len(R) != lg_n * ctx.point_bytes:
+                raise VerificationError("bp_ipp_verify_batch: proof %d has the wrong number of L/R points" % i)
+            keep.append(bufs)
+            arr[i].transcript = tr.h
+            for name, bf in zip(("P_le", "Q_le", "a_le32", "b_le32", "L_le", "R_le"), bufs):
+                setattr(arr[i], name, ctypes.cast(bf, ctypes.c_void_p))
+        if weights is None:
+            weights = b"".join(os.urandom(16) + bytes(16) for _ in range(m))
+        if len(weights) != 32 * m:
+            raise ArgError("bp_ipp_verify_batch: need one 32-byte weight per proof")
+        _check(lib().bp_ipp_verify_batch(ctx.h, n, lg_n, G_factors.h, H_factors.h, G.h, H.h, ctypes.cast(arr, ctypes.c_void_p), m,
+                                         bytes(weights) if m else b"\0"), "bp_ipp_verify_batch")
 
     @staticmethod
     def verification_scalars(curve, L_le, R_le, n, transcript):

@@ -194,18 +194,41 @@ struct Ipp {
     }
 
     // IPP::verification_scalars, src/ipp.rs:262-315 (host: O(lg n) transcript work + O(n) Fr products)
-    static int verification_scalars(Transcript& t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, std::vector<Fe<F>>& ch,
-                                    std::vector<Fe<F>>& ch_inv) {
+    // FieldElement::batch_invert (src/ipp.rs:295): Montgomery's trick, one inversion + 3 products per element;
+    // zero stays zero (as the Fermat inverse does).
+    static void batch_invert(const std::vector<Fe<F>>& in, std::vector<Fe<F>>& out) {
+        size_t k = in.size();
+        out.assign(k, fe_zero<F>());
+        std::vector<Fe<F>> prefix(k);
+        Fe<F> acc = fe_one<F>();
+        for (size_t i = 0; i < k; i++) { prefix[i] = acc; if (!fe_is_zero(in[i])) acc = fe_mul(acc, in[i]); }
+        Fe<F> inv = fe_inv<F>(acc);
+        for (size_t i = k; i-- > 0;) {
+            if (fe_is_zero(in[i])) continue;
+            out[i] = fe_mul(inv, prefix[i]);
+            inv = fe_mul(inv, in[i]);
+        }
+    }
+
+    // the transcript half of verification_scalars: challenges u_j in creation order (src/ipp.rs:269-288)
+    static int verification_challenges(Transcript& t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, std::vector<Fe<F>>& ch) {
         if (lg_n >= 32) return BP_ERR_VERIFY;                                           // :269-273
         if (n != ((size_t)1 << lg_n)) return BP_ERR_VERIFY;                             // :274-276
         ipp_domain_sep(t, n);                                                           // :278
-        ch.resize(lg_n); ch_inv.resize(lg_n);
+        ch.resize(lg_n);
         for (size_t j = 0; j < lg_n; j++) {                                             // :283-288
             commit_point(t, "L", L_le + j * 2 * kFb);
             commit_point(t, "R", R_le + j * 2 * kFb);
             ch[j] = challenge_scalar(t, "u");
-            ch_inv[j] = fe_inv<F>(ch[j]);                                               // batch_invert :295 (same values)
         }
+        return BP_OK;
+    }
+
+    static int verification_scalars(Transcript& t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, std::vector<Fe<F>>& ch,
+                                    std::vector<Fe<F>>& ch_inv) {
+        int rc = verification_challenges(t, L_le, R_le, lg_n, n, ch);
+        if (rc) return rc;
+        batch_invert(ch, ch_inv);                                                       // :295
         return BP_OK;
     }
 
@@ -258,6 +281,73 @@ struct Ipp {
         cleanup();
         if (rc) return rc;
         return memcmp(expect, P_le, 2 * kFb) == 0 ? BP_OK : BP_ERR_VERIFY;              // :255-259
+    }
+
+    // m proofs, same n / generators / factors: one MSM of 2n + m (2 lg n + 2) terms that must be the identity.
+    static int verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* Gf, const bp_frvec* Hf, const bp_g1vec* G, const bp_g1vec* H,
+                            const bp_ipp_proof_ref* proofs, size_t m, const uint8_t* weights_le32) {
+        const size_t per = 2 * lg_n + 2;                 // Q, L.., R.., P
+        const size_t total = 2 * n + m * per;
+        std::vector<ScalarWords> hch(m * lg_n ? m * lg_n : 1), hchi(m * lg_n ? m * lg_n : 1), hwa(m), hwb(m), tail(m * per);
+        std::vector<uint8_t> hraw(m * per * 2 * kFb);
+        std::vector<Fe<F>> all_ch, all_inv;
+        all_ch.reserve(m * lg_n);
+        for (size_t p = 0; p < m; p++) {
+            std::vector<Fe<F>> ch;
+            int rc = verification_challenges(proofs[p].transcript->t, proofs[p].L_le, proofs[p].R_le, lg_n, n, ch);
+            if (rc) return rc;
+            all_ch.insert(all_ch.end(), ch.begin(), ch.end());
+        }
+        batch_invert(all_ch, all_inv);                   // one field inversion for the whole batch
+        for (size_t p = 0; p < m; p++) {
+            const bp_ipp_proof_ref& pr = proofs[p];
+            const Fe<F>* ch = all_ch.data() + p * lg_n;
+            const Fe<F>* ch_inv = all_inv.data() + p * lg_n;
+            Fe<F> w = fr_from_le<F>(weights_le32 + 32 * p), a = fr_from_le<F>(pr.a_le32), b = fr_from_le<F>(pr.b_le32);
+            Fe<F> wa = fe_mul(w, a), wb = fe_mul(w, b);
+            hwa[p] = fr_mont_words<F>(wa);
+            hwb[p] = fr_mont_words<F>(wb);
+            ScalarWords* tl = &tail[p * per];
+            uint8_t* rw = &hraw[p * per * 2 * kFb];
+            auto put = [&](size_t k, const Fe<F>& x_mont) { uint32_t wd[8]; fe_pack_words<F>(wd, fe_from_mont<F>(x_mont)); memcpy(tl[k].w, wd, 32); };
+            put(0, fe_mul(wa, b));                                                       // w a b   on Q
+            memcpy(rw, pr.Q_le, 2 * kFb);
+            for (size_t j = 0; j < lg_n; j++) {
+                hch[p * lg_n + j] = fr_mont_words<F>(ch[j]);
+                hchi[p * lg_n + j] = fr_mont_words<F>(ch_inv[j]);
+                put(1 + j, fe_neg(fe_mul(w, fe_sqr(ch[j]))));                            // -w u_j^2   on L_j
+                put(1 + lg_n + j, fe_neg(fe_mul(w, fe_sqr(ch_inv[j]))));                 // -w u_j^-2  on R_j
+            }
+            if (lg_n) { memcpy(rw + 2 * kFb, pr.L_le, lg_n * 2 * kFb); memcpy(rw + (1 + lg_n) * 2 * kFb, pr.R_le, lg_n * 2 * kFb); }
+            put(1 + 2 * lg_n, fe_neg(w));                                                // -w        on P
+            memcpy(rw + (1 + 2 * lg_n) * 2 * kFb, pr.P_le, 2 * kFb);
+        }
+        void *pts = nullptr, *sc = nullptr, *chd = nullptr, *raw = nullptr;
+        auto cleanup = [&]() { if (pts) (void)hipFree(pts); if (sc) (void)hipFree(sc); if (chd) (void)hipFree(chd); if (raw) (void)hipFree(raw); };
+        const size_t nch = hch.size();
+        if (hipMalloc(&pts, total * kPt) != hipSuccess || hipMalloc(&sc, total * 32) != hipSuccess ||
+            hipMalloc(&chd, (2 * nch + 2 * m) * 32) != hipSuccess || hipMalloc(&raw, hraw.size()) != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+        ScalarWords *d_ch = (ScalarWords*)chd, *d_chi = d_ch + nch, *d_wa = d_chi + nch, *d_wb = d_wa + m;
+        hipStream_t s = ctx->stream;
+        bool ok = hipMemcpyAsync(d_ch, hch.data(), nch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(d_chi, hchi.data(), nch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(d_wa, hwa.data(), m * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(d_wb, hwb.data(), m * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync((uint8_t*)sc + 2 * n * 32, tail.data(), m * per * 32, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok) { cleanup(); return BP_ERR_DEVICE; }
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(m * per)), dim3(kBlock), 0, s, (const uint32_t*)raw, m * per, (AffPacked<C>*)pts + 2 * n);
+        hipLaunchKernelGGL(k_ipp_verify_terms_batch<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
+                           (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, d_ch, d_chi, d_wa, d_wb, (int)lg_n, m, n, (AffPacked<C>*)pts,
+                           (ScalarWords*)sc);
+        if (hipGetLastError() != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+        uint8_t got[2 * kFb];
+        int rc = bp_internal_msm(ctx, pts, sc, total, got);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : BP_ERR_DEVICE;
+        cleanup();
+        if (rc) return rc;
+        for (size_t k = 0; k < 2 * kFb; k++) if (got[k]) return BP_ERR_VERIFY;          // identity = all-zero bytes
+        return BP_OK;
     }
 };
 
@@ -681,6 +771,20 @@ int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_fac
     if (G->n < n || H->n < n || G_factors->n < n || H_factors->n < n) return BP_ERR_LENGTH;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     IPP_DISPATCH(ctx->curve, I::verify(ctx, t->t, n, G_factors, H_factors, P_le, Q_le, G, H, a_le32, b_le32, L_le, R_le, lg_n));
+}
+
+int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
+                        const bp_g1vec* H, const bp_ipp_proof_ref* proofs, size_t m, const uint8_t* weights_le32) {
+    if (!ctx || !G_factors || !H_factors || !G || !H || (m && (!proofs || !weights_le32))) return BP_ERR_ARG;
+    for (size_t p = 0; p < m; p++) {
+        const bp_ipp_proof_ref& r = proofs[p];
+        if (!r.transcript || !r.P_le || !r.Q_le || !r.a_le32 || !r.b_le32 || (lg_n && (!r.L_le || !r.R_le))) return BP_ERR_ARG;
+    }
+    if (lg_n >= 32 || n != ((size_t)1 << lg_n)) return BP_ERR_VERIFY;
+    if (G->n < n || H->n < n || G_factors->n < n || H_factors->n < n) return BP_ERR_LENGTH;
+    if (m == 0) return BP_OK;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    IPP_DISPATCH(ctx->curve, I::verify_batch(ctx, n, lg_n, G_factors, H_factors, G, H, proofs, m, weights_le32));
 }
 
 // IPP::verification_scalars (ipp.rs:262-315): (u_j^2, u_j^-2, s) as canonical LE scalars; host arithmetic.

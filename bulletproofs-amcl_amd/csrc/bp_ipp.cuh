@@ -454,4 +454,38 @@ __global__ void __launch_bounds__(kBlock) k_ipp_verify_terms(const AffPacked<C>*
     pts[1 + n + i] = H[i];
 }
 
+// Batch verification of m proofs over the SAME generators (the random-linear-combination argument of
+// src/r1cs/verifier.rs:392 applied across proofs): sum_j w_j * (check_j) == O with caller-chosen random weights w_j.
+//   sc[i]     = Gf_i * sum_j (w_j a_j) s_(j,i)           (points G)
+//   sc[n + i] = Hf_i * sum_j (w_j b_j) / s_(j,i)         (points H)
+// ch / ch_inv: m blocks of lg_n challenges (Montgomery form); wa / wb: m products w_j a_j, w_j b_j (Montgomery form).
+// The per-proof tail (Q_j, L_j, R_j, P_j with scalars w_j a_j b_j, -w_j u^2, -w_j u^-2, -w_j) is assembled by the host side.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_ipp_verify_terms_batch(const AffPacked<C>* __restrict__ G, const AffPacked<C>* __restrict__ H,
+                                                                   const ScalarWords* __restrict__ gf, const ScalarWords* __restrict__ hf,
+                                                                   const ScalarWords* __restrict__ ch, const ScalarWords* __restrict__ ch_inv,
+                                                                   const ScalarWords* __restrict__ wa, const ScalarWords* __restrict__ wb, int lg_n,
+                                                                   size_t m, size_t n, AffPacked<C>* __restrict__ pts, ScalarWords* __restrict__ sc) {
+    using F = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> gacc = fe_zero<F>(), hacc = fe_zero<F>();
+    for (size_t p = 0; p < m; p++) {
+        Fe<F> s = fr_load<F>(wa, p), sinv = fr_load<F>(wb, p);
+        for (int j = 0; j < lg_n; j++) {
+            bool bit = (i >> (lg_n - 1 - j)) & 1;
+            Fe<F> uj = fr_load<F>(ch, p * lg_n + j), ujinv = fr_load<F>(ch_inv, p * lg_n + j);
+            s = fe_mul(s, bit ? uj : ujinv);
+            sinv = fe_mul(sinv, bit ? ujinv : uj);
+        }
+        gacc = fe_add(gacc, s);
+        hacc = fe_add(hacc, sinv);
+    }
+    // Montgomery accumulators times canonical factors -> canonical scalars
+    fr_store<F>(sc, i, fe_mul(gacc, fr_load<F>(gf, i)));
+    fr_store<F>(sc, n + i, fe_mul(hacc, fr_load<F>(hf, i)));
+    pts[i] = G[i];
+    pts[n + i] = H[i];
+}
+
 }  // namespace bp

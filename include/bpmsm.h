@@ -230,6 +230,25 @@ int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_f
 int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_factors, const bp_frvec* H_factors, const uint8_t* P_le,
                   const uint8_t* Q_le, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* a_le32, const uint8_t* b_le32, const uint8_t* L_le,
                   const uint8_t* R_le, size_t lg_n);
+/* Batch verification: m proofs of the same length n over the same generators and factors are accepted
+ * together iff  sum_j w_j * (G^(a_j s_j) H^(b_j / s_j) Q_j^(a_j b_j) - P_j - sum_k (u_jk^2 L_jk + u_jk^-2 R_jk)) == O,
+ * i.e. ONE MSM of 2n + m (2 lg n + 2) terms instead of m MSMs of 2n + 2 lg n + 1 -- the random-linear-combination
+ * argument the reference's verifier already uses inside one proof (src/r1cs/verifier.rs:392) applied across proofs.
+ * weights_le32: m canonical scalars chosen by the caller AFTER the proofs are fixed, from a source the provers cannot
+ * predict (128 random bits each are enough); a forged proof then passes with probability ~ 1/r.  BP_ERR_VERIFY does
+ * not say which proof failed: fall back to bp_ipp_verify per proof.  Each transcript is advanced exactly as by
+ * bp_ipp_verify. */
+typedef struct bp_ipp_proof_ref {
+    bp_transcript* transcript;
+    const uint8_t* P_le;      /* commitment, x || y little-endian */
+    const uint8_t* Q_le;
+    const uint8_t* a_le32;
+    const uint8_t* b_le32;
+    const uint8_t* L_le;      /* lg_n points */
+    const uint8_t* R_le;
+} bp_ipp_proof_ref;
+int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
+                        const bp_g1vec* H, const bp_ipp_proof_ref* proofs, size_t m, const uint8_t* weights_le32);
 /* IPP::verification_scalars (src/ipp.rs:262-315): u_sq / u_inv_sq (lg_n scalars each) and s (n scalars), 32-byte LE.
  * Host arithmetic (used by the R1CS verifier, src/r1cs/verifier.rs:354); no GPU needed. */
 int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, uint8_t* u_sq,

@@ -214,6 +214,27 @@ struct IPP {
                             a.data(), b.data(), L_vec.data(), R_vec.data(), L_vec.size() / ctx.point_bytes()),
               "bp_ipp_verify");
     }
+    // m proofs over the same generators in ONE MSM (random linear combination across proofs, bp_ipp_verify_batch).
+    // weights: m 32-byte LE scalars drawn by the caller after the proofs are fixed.  Throws VerificationError if the
+    // combination is not the identity (it does not say which proof is bad: fall back to verify_ipp per proof).
+    struct BatchItem {
+        Transcript* transcript;
+        const Bytes* P; const Bytes* Q; const InnerProductArgumentProof* proof;
+    };
+    static void verify_batch(Context& ctx, size_t n, const FieldElementVector& G_factors, const FieldElementVector& H_factors, const G1Vector& G,
+                             const G1Vector& H, const std::vector<BatchItem>& items, const Bytes& weights) {
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        std::vector<bp_ipp_proof_ref> refs(items.size());
+        for (size_t i = 0; i < items.size(); i++) {
+            const InnerProductArgumentProof& p = *items[i].proof;
+            if (p.L.size() != lg * ctx.point_bytes() || p.R.size() != lg * ctx.point_bytes()) throw VerificationError("bp_ipp_verify_batch", BP_ERR_VERIFY);
+            refs[i] = bp_ipp_proof_ref{items[i].transcript->handle(), items[i].P->data(), items[i].Q->data(), p.a.data(), p.b.data(), p.L.data(), p.R.data()};
+        }
+        if (weights.size() != 32 * items.size()) throw ArgError("bp_ipp_verify_batch", BP_ERR_ARG);
+        check(bp_ipp_verify_batch(ctx.handle(), n, lg, G_factors.handle(), H_factors.handle(), G.handle(), H.handle(), refs.data(), refs.size(), weights.data()),
+              "bp_ipp_verify_batch");
+    }
     // src/ipp.rs:262-315: (u_sq, u_inv_sq, s)
     static void verification_scalars(int curve, size_t point_bytes, const Bytes& L_vec, const Bytes& R_vec, size_t n, Transcript& transcript, Bytes& u_sq,
                                      Bytes& u_inv_sq, Bytes& s) {

@@ -49,6 +49,30 @@ static int gpu_mode(int curve) {
     catch (const bp::ValueError&) {}
     try { bp::Transcript t4("x"); bp::FieldElementVector three(ctx, ints({1, 2, 3})); bp::IPP::create_ipp(ctx, t4, Q, G_factors, H_factors, G, H, a, three); printf("unequal lengths accepted\n"); return 1; }
     catch (const bp::ArgError&) {}
+    // the reference's own generator construction (src/ipp.rs:340-342) through the mirror, then the same proof again and
+    // both proofs verified in one batch
+    bp::G1Vector Gh = bp::G1Vector::get_generators(ctx, "g", n), Hh = bp::G1Vector::get_generators(ctx, "h", n);
+    bp::Bytes Qh = bp::G1Vector::from_msg_hash(ctx, {"Q"}).to_bytes();
+    if (Gh.len() != n || Qh.size() != ctx.point_bytes() || Gh.to_bytes() == G.to_bytes()) { printf("get_generators wrong\n"); return 1; }
+    bp::Transcript t5("innerproduct");
+    bp::InnerProductArgumentProof proof2 = bp::IPP::create_ipp(ctx, t5, Qh, G_factors, H_factors, Gh, Hh, a, b);
+    bp::G1Vector pts2(ctx, concat({Gh.to_bytes(), Hh.to_bytes(), Qh}));
+    bp::Bytes P2 = pts2.multi_scalar_mul_var_time(sc);
+    bp::InnerProductArgumentProof proof3 = proof2;      // a second proof over the same generators: other Q
+    bp::Bytes Q3 = bp::G1Vector::from_msg_hash(ctx, {"Q3"}).to_bytes();
+    { bp::Transcript t6("innerproduct"); proof3 = bp::IPP::create_ipp(ctx, t6, Q3, G_factors, H_factors, Gh, Hh, a, b); }
+    bp::G1Vector pts3(ctx, concat({Gh.to_bytes(), Hh.to_bytes(), Q3}));
+    bp::Bytes P3 = pts3.multi_scalar_mul_var_time(sc);
+    bp::Bytes weights = concat({scalar(0x9e3779b97f4a7c15ull), scalar(0xc2b2ae3d27d4eb4full)});
+    {
+        bp::Transcript ta("innerproduct"), tb("innerproduct");
+        bp::IPP::verify_batch(ctx, n, G_factors, H_factors, Gh, Hh, {{&ta, &P2, &Qh, &proof2}, {&tb, &P3, &Q3, &proof3}}, weights);
+    }
+    try {
+        bp::Transcript ta("innerproduct"), tb("innerproduct");
+        bp::IPP::verify_batch(ctx, n, G_factors, H_factors, Gh, Hh, {{&ta, &P2, &Qh, &proof2}, {&tb, &P2, &Q3, &proof3}}, weights);   // wrong commitment
+        printf("bad batch accepted\n"); return 1;
+    } catch (const bp::VerificationError&) {}
     printf("cpp gpu ok curve=%d a=%s\n", curve, hex(proof.a).c_str());
     return 0;
 }

@@ -273,3 +273,56 @@ def test_ipp_bn254_n4096_config5(bp, ctxs):
     bad = bytearray(proof.b); bad[0] ^= 1
     with pytest.raises(bp.VerificationError):
         bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, bytes(bad), proof.L, proof.R)
+
+
+@pytest.mark.parametrize("name,n,unit_gf,m", [("bls12_381", 64, True, 9), ("bls12_381", 1, True, 3), ("bn254", 32, False, 5),
+                                               ("bls12_381", 2, False, 1)])
+def test_ipp_verify_batch(bp, ctxs, name, n, unit_gf, m):
+    """bp_ipp_verify_batch: m proofs over the same generators pass together iff each passes alone."""
+    ctx = ctxs[name]
+    cid = ctx.curve
+    Gv, Hv, _, Gf, Hf, _, _ = make_instance(bp, ctx, n, 9100 + n, unit_gf)
+    items = []
+    for j in range(m):
+        Q = O.g1_mul(cid, O.random_scalars(cid, 9200 + j, 1), O.generator(cid))
+        a = bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, 9300 + j, n), n)
+        b = bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, 9400 + j, n), n)
+        label = b"proof-%d" % j
+        proof = bp.IPP.create_ipp(ctx, bp.Transcript(label), Q, Gf, Hf, Gv, Hv, a, b)
+        P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+        bp.IPP.verify_ipp(ctx, n, bp.Transcript(label), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+        items.append((label, P, Q, proof))
+
+    def refs(mutate=None):
+        out = []
+        for j, (label, P, Q, pr) in enumerate(items):
+            f = {"P": P, "Q": Q, "a": pr.a, "b": pr.b, "L": pr.L, "R": pr.R}
+            if mutate and mutate[0] == j:
+                f[mutate[1]] = mutate[2](f[mutate[1]])
+            out.append((bp.Transcript(label), f["P"], f["Q"], f["a"], f["b"], f["L"], f["R"]))
+        return out
+
+    good = refs()
+    bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, good)                                 # fresh random 128-bit weights
+    # every transcript ends where the single-proof verifier leaves it
+    single = bp.Transcript(items[0][0])
+    bp.IPP.verify_ipp(ctx, n, single, Gf, Hf, items[0][1], items[0][2], Gv, Hv, items[0][3].a, items[0][3].b, items[0][3].L, items[0][3].R)
+    assert good[0][0].challenge_bytes(b"after", 32) == single.challenge_bytes(b"after", 32)
+    fixed = b"".join(O.random_scalars(cid, 9500 + j, 1) for j in range(m))            # full-width weights work as well
+    bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, refs(), weights=fixed)
+    bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, [])                                    # nothing to check
+
+    def bump(x):                                                                       # scalar + 1 mod r
+        return ((int.from_bytes(x, "little") + 1) % ctx.r).to_bytes(32, "little")
+
+    def swap_first(pts):                                                               # replace the first point by the generator
+        return O.generator(cid) + pts[ctx.point_bytes:]
+
+    bad_cases = [(m - 1, "a", bump), (0, "b", bump), (m // 2, "P", swap_first), (m // 2, "Q", swap_first)]
+    if n > 1:
+        bad_cases += [(0, "L", swap_first), (m - 1, "R", swap_first)]
+    for mut in bad_cases:
+        with pytest.raises(bp.VerificationError):
+            bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, refs(mut))
+    with pytest.raises(bp.VerificationError):                                          # wrong n for these proofs
+        bp.IPP.verify_batch(ctx, 2 * n, Gf, Hf, Gv, Hv, refs())
