@@ -13,7 +13,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libbpmsm.so")
+_SO = os.environ.get("BPMSM_SO") or os.path.join(_HERE, "libbpmsm.so")   # override: another build of the SAME library (sanitizer runs)
 
 BP_OK, BP_ERR_LENGTH, BP_ERR_ARG, BP_ERR_VERIFY, BP_ERR_DEVICE = 0, 1, 2, 3, 4
 BLS12_381, BN254 = 0, 1

@@ -6,7 +6,7 @@ import subprocess
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "oracle")
-_SO = os.path.join(_DIR, "liboracle.so")
+_SO = os.environ.get("BP_ORACLE_SO") or os.path.join(_DIR, "liboracle.so")   # override: sanitizer builds (scripts/sanitize_cpu.sh)
 
 BLS12_381, BN254 = 0, 1
 CURVE_IDS = {"bls12_381": 0, "bn254": 1}
