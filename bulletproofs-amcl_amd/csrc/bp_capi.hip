@@ -1,6 +1,7 @@
 // bp_capi.hip -- implementation of the C ABI in include/bpmsm.h (libbpmsm.so).
 // Host orchestration of the gfx950 kernels in bp_kernels.cuh; no CPU fallback for any compute entry point.
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "bp_internal.hpp"
@@ -82,10 +83,20 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
     t.nbuckets = nb;
     memcpy(t.bias.w, bias, sizeof bias);
     static const uint32_t m_env = getenv("BP_REDUCE_M") ? (uint32_t)atoi(getenv("BP_REDUCE_M")) : 0;
+    // Buckets per reduce thread: the smallest m whose ACTIVE blocks (blocks past a window's last bucket exit at once) fit one
+    // per CU.  k_bucket_reduce is a chain of ~2m + 30 dependent point operations per lane; a 257th block makes some SIMD run
+    // two such chains back to back (measured: c = 14 paired, 304 blocks 1.26 ms, 152 blocks 0.86 ms; scripts/time_pair.py).
     uint32_t m = 1;
-    while (m < 8 && nb / m > 65536) m <<= 1;
+    for (; m < 16; m++) {
+        uint32_t blocks = 0;
+        for (int w = 0; w < W; w++) { uint32_t B = t.boff[w + 1] - t.boff[w]; blocks += ((B + m - 1) / m + kBlock - 1) / kBlock; }
+        if (blocks <= 256) break;
+    }
     if (m_env) m = m_env;
     g.m = m;
+    uint32_t rb = 0;
+    for (int w = 0; w < W; w++) { t.rboff[w] = (uint16_t)rb; uint32_t B = t.boff[w + 1] - t.boff[w]; rb += ((B + m - 1) / m + kBlock - 1) / kBlock; }
+    t.rboff[W] = (uint16_t)rb;   // <= 256 by the choice of m unless m hit its cap (c = 16, two sets, m = 16: 256)
     uint32_t T = (maxB + m - 1) / m;
     g.bpw = (T + kBlock - 1) / kBlock;
 }
@@ -142,7 +153,7 @@ struct Impl {
         if ((rc = ctx->tsum.reserve(max_tasks * kXyzzBytes))) return rc;
         if ((rc = ctx->heavy.reserve(max_heavy * 4))) return rc;
         if ((rc = ctx->meta.reserve((kTaskBins + 2) * 4))) return rc;
-        if ((rc = ctx->partial.reserve((size_t)W * g.bpw * kXyzzBytes))) return rc;
+        if ((rc = ctx->partial.reserve((size_t)tab.rboff[W] * kXyzzBytes))) return rc;
         if ((rc = ctx->window_sum.reserve((size_t)W * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // histogram, then bucket starts
         uint32_t* cursor = (uint32_t*)ctx->cursor.p;     // scatter cursors, then bucket ends
@@ -216,9 +227,9 @@ struct Impl {
         hipLaunchKernelGGL(k_combine_light<C>, dim3(bgrid), dim3(kBlock), 0, st, task_off, ntasks, (uint32_t)nb, tsum);
         hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)max_heavy), dim3(64), 0, st, heavy, nheavy, task_off, ntasks, tsum);
         BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
-        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(g.bpw, W), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
         BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
-        hipLaunchKernelGGL(k_window_sums<C>, dim3(W), dim3(kBlock), 0, st, partial, g.bpw, wsum);
+        hipLaunchKernelGGL(k_window_sums<C>, dim3(W), dim3(kBlock), 0, st, partial, tab, wsum);
         BP_TRACE_SYNC(ctx, "k_window_sums<C>");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
         HIPCHK(hipGetLastError());
@@ -319,8 +330,12 @@ struct Impl {
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, W1, g.tab.cw, out1_le);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned + W1, 1, W1, g.tab.cw + W1, out2_le);
+        // the two serial tails (~0.12 ms each: 255 dependent doublings) are independent: fold the second on another thread
+        const host::Tail<C>& tl = tail();
+        const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
+        std::thread second([&]() { tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le); });
+        tl.fold(rec, 1, W1, g.tab.cw, out1_le);
+        second.join();
         return BP_OK;
     }
 

@@ -51,6 +51,7 @@ struct WinTab {
     uint32_t boff[kMaxWindows + 1];
     uint8_t fbits[kMaxWindows];        // fine bits of a bucket id: min(8, cw - 1); the rest are the coarse bin
     uint16_t hoff[kMaxWindows + 1];    // first coarse-bin row of window w in the tile histogram (hoff[W] = rows)
+    uint16_t rboff[kMaxWindows + 1];   // first block of window w in the (compact, 1-D) grid of k_bucket_reduce
     ScalarWords bias;   // H = sum_w (2^(cw-1) - 1) 2^off[w]
 };
 
@@ -424,22 +425,23 @@ __device__ __forceinline__ Xyzz<C> xyzz_mul_small(uint32_t k, const Xyzz<C>& p) 
     return acc;
 }
 
-// grid = (max blocks per window, W).  Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket
-// indices t*m .. t*m + m - 1, and produces  sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
+// grid = tab.rboff[W] blocks, window w owning blocks rboff[w] .. rboff[w+1]-1 (exactly the blocks that have buckets: with a
+// 2-D grid padded to the widest window, the blocks that exit at once skewed the dispatch and some CUs ran two of these long
+// dependent chains back to back -- 1.00 ms instead of 0.54 ms at n = 2^16, c = 14; profiles/r01_reduce_grid_*.txt).
+// Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket indices t*m .. t*m + m - 1, and produces
+//   sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
 // Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t m,
                                                           XyzzPacked<C>* __restrict__ partial) {
     __shared__ XyzzPacked<C> lds[kBlock];
-    uint32_t w = blockIdx.y;
+    uint32_t w = 0;
+    while (w + 1 < (uint32_t)tab.W && tab.rboff[w + 1] <= blockIdx.x) w++;   // uniform scan, W <= 256
+    const uint32_t bx = blockIdx.x - tab.rboff[w];
     uint32_t B = tab.boff[w + 1] - tab.boff[w];
-    uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t t = bx * kBlock + threadIdx.x;
     uint32_t T = (B + m - 1) / m;
-    if (blockIdx.x * kBlock >= T) {   // whole block beyond this window's buckets
-        if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = xyzz_pack(xyzz_inf<C>());
-        return;
-    }
     Xyzz<C> mine = xyzz_inf<C>();
     if (t < T) {
         Xyzz<C> run = xyzz_inf<C>(), tri = xyzz_inf<C>();
@@ -451,19 +453,19 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
         }
         mine = xyzz_add(tri, xyzz_mul_small<C>(lo, run));
     }
-    uint32_t live = T - blockIdx.x * kBlock;
+    uint32_t live = T - bx * kBlock;
     mine = block_tree_sum<C>(mine, lds, live < (uint32_t)kBlock ? (int)live : kBlock);
-    if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = xyzz_pack(mine);
+    if (threadIdx.x == 0) partial[blockIdx.x] = xyzz_pack(mine);
 }
 
-// grid = W blocks: window_sum[w] = sum of partial[w][0..per_window)
+// grid = W blocks: window_sum[w] = sum of partial[rboff[w] .. rboff[w+1])
 template <class C>
-__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, uint32_t per_window,
-                                                        XyzzPacked<C>* __restrict__ window_sum) {
+__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, WinTab tab, XyzzPacked<C>* __restrict__ window_sum) {
     __shared__ XyzzPacked<C> lds[kBlock];
     uint32_t w = blockIdx.x;
+    const uint32_t first = tab.rboff[w], per_window = tab.rboff[w + 1] - first;
     Xyzz<C> mine = xyzz_inf<C>();
-    for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_add(mine, xyzz_unpack(partial[(size_t)w * per_window + j]));
+    for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_add(mine, xyzz_unpack(partial[first + j]));
     mine = block_tree_sum<C>(mine, lds, per_window < (uint32_t)kBlock ? (int)per_window : kBlock);
     if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
 }
