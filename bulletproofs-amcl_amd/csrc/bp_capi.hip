@@ -152,7 +152,9 @@ struct Impl {
         if ((rc = ctx->t_len.reserve(max_tasks * 4))) return rc;
         if ((rc = ctx->tsum.reserve(max_tasks * kXyzzBytes))) return rc;
         if ((rc = ctx->heavy.reserve(max_heavy * 4))) return rc;
-        if ((rc = ctx->meta.reserve((kTaskBins + 2) * 4))) return rc;
+        const size_t max_chunks = max_heavy + max_tasks / kBlock + 1;
+        if ((rc = ctx->heavy_chunks.reserve(max_chunks * sizeof(uint2)))) return rc;
+        if ((rc = ctx->meta.reserve((kTaskBins + 3) * 4))) return rc;
         if ((rc = ctx->partial.reserve((size_t)tab.rboff[W] * kXyzzBytes))) return rc;
         if ((rc = ctx->window_sum.reserve((size_t)W * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // histogram, then bucket starts
@@ -169,13 +171,15 @@ struct Impl {
         uint32_t* bins = (uint32_t*)ctx->meta.p;          // [kTaskBins] bin counts -> bin cursors
         uint32_t* total_tasks = bins + kTaskBins;
         uint32_t* nheavy = bins + kTaskBins + 1;
+        uint32_t* nchunks = bins + kTaskBins + 2;
+        uint2* chunks = (uint2*)ctx->heavy_chunks.p;
         auto* tsum = (XyzzPacked<C>*)ctx->tsum.p;
         auto* partial = (XyzzPacked<C>*)ctx->partial.p;
         auto* wsum = (XyzzPacked<C>*)ctx->window_sum.p;
 
         bool tm = ctx->timing;
         if (tm) { if ((rc = ensure_events(ctx))) return rc; HIPCHK(hipEventRecord(ctx->ev[0], st)); }
-        HIPCHK(hipMemsetAsync(bins, 0, (kTaskBins + 2) * 4, st));
+        HIPCHK(hipMemsetAsync(bins, 0, (kTaskBins + 3) * 4, st));
         const uint32_t ntiles = (uint32_t)((n + kTile - 1) / kTile);
         const uint32_t rows = tab.hoff[W];
         const size_t nhist = (size_t)rows * ntiles;
@@ -213,7 +217,7 @@ struct Impl {
         BP_TRACE_SYNC(ctx, "k_scan_top");
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum, task_off, (uint32_t*)nullptr);
         BP_TRACE_SYNC(ctx, "k_scan_apply");
-        hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len, heavy, nheavy);
+        hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len, heavy, nheavy, chunks, nchunks);
         BP_TRACE_SYNC(ctx, "k_task_emit");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));
         {
@@ -224,10 +228,13 @@ struct Impl {
             else hipLaunchKernelGGL((k_accumulate<C, 3>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
         }
         if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
-        hipLaunchKernelGGL(k_combine_light<C>, dim3(bgrid), dim3(kBlock), 0, st, task_off, ntasks, (uint32_t)nb, tsum);
-        hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)max_heavy), dim3(64), 0, st, heavy, nheavy, task_off, ntasks, tsum);
+        static const bool fuse = getenv("BP_FUSE_COMBINE") ? atoi(getenv("BP_FUSE_COMBINE")) != 0 : true;
+        if (!fuse) hipLaunchKernelGGL(k_combine_light<C>, dim3(bgrid), dim3(kBlock), 0, st, task_off, ntasks, (uint32_t)nb, tsum);
+        hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(max_chunks < 1024 ? max_chunks : 1024)), dim3(kBlock), 0, st, chunks, nchunks, task_off, ntasks, tsum);
+        hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)(max_heavy < 256 ? max_heavy : 256)), dim3(kBlock), 0, st, heavy, nheavy, task_off, ntasks, tsum);
         BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
-        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
+        if (fuse) hipLaunchKernelGGL((k_bucket_reduce<C, true>), dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
+        else hipLaunchKernelGGL((k_bucket_reduce<C, false>), dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
         BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
         hipLaunchKernelGGL(k_window_sums<C>, dim3(W), dim3(kBlock), 0, st, partial, tab, wsum);
         BP_TRACE_SYNC(ctx, "k_window_sums<C>");
@@ -500,7 +507,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->fixed_base_table.release();
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_code, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
-                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch}) b->release();
+                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch}) b->release();
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->ev_ready) for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -295,11 +295,12 @@ static __global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __re
 
 // thread per bucket: emit its tasks.  task id = task_off[g] + k; order[] lists task ids longest first (positions are
 // reserved per block through LDS histograms: one global atomic per (block, length class)).  t_start/t_len describe the
-// slot range of a task.  Buckets with more than kLightMax tasks are appended to heavy[].
+// slot range of a task.  Buckets with more than kLightMax tasks are appended to heavy[], their kBlock-task chunks to chunks[].
 static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
                                                        uint32_t L, uint32_t lshift, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ bin_cursor,
                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ t_start, uint32_t* __restrict__ t_len,
-                                                       uint32_t* __restrict__ heavy, uint32_t* __restrict__ nheavy) {
+                                                       uint32_t* __restrict__ heavy, uint32_t* __restrict__ nheavy, uint2* __restrict__ chunks,
+                                                       uint32_t* __restrict__ nchunks) {
     __shared__ uint32_t lh[kTaskBins], lbase[kTaskBins];
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
     __syncthreads();
@@ -328,7 +329,13 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
         t_start[toff + nfull] = s0 + nfull * L;
         t_len[toff + nfull] = rem;
     }
-    if (nfull + (rem ? 1u : 0u) > kLightMax) heavy[atomicAdd(nheavy, 1u)] = g;
+    const uint32_t nt = nfull + (rem ? 1u : 0u);
+    if (nt > kLightMax) {
+        heavy[atomicAdd(nheavy, 1u)] = g;
+        const uint32_t nch = (nt + kBlock - 1) / kBlock;          // chunks of kBlock task sums for k_combine_chunks
+        const uint32_t base = atomicAdd(nchunks, nch);
+        for (uint32_t j = 0; j < nch; j++) chunks[base + j] = make_uint2(g, j);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- bucket accumulate
@@ -389,27 +396,46 @@ __global__ void __launch_bounds__(kBlock) k_combine_light(const uint32_t* __rest
     tsum[t0] = xyzz_pack(acc);
 }
 
-// One wave per heavy bucket (grid = an upper bound; surplus waves exit): sum of its tasks -> tsum[task_off[g]].
+// Heavy buckets (more than kLightMax tasks) are folded in two stages so that one bucket holding most of the points -- 0/1
+// scalars, the a_L / a_R commitments of a range proof, put half of all points into ONE bucket: 4096 task sums at n = 2^16 --
+// is a tree over many blocks instead of one long chain (one wave: 64 + 6 dependent additions, 1.23 ms; chunked: 8 + 1 + 4):
+//   k_combine_chunks  block per (bucket, chunk of kBlock task sums), grid-stride over chunks[]: tree -> first record of the chunk
+//   k_combine_heavy   block per heavy bucket, grid-stride over heavy[]: sum of its chunk sums -> tsum[task_off[g]]
+// List lengths are only known on the device, so both grids are fixed-size and stride.
 template <class C>
-__global__ void __launch_bounds__(64) k_combine_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ nheavy,
-                                                      const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks,
-                                                      XyzzPacked<C>* __restrict__ tsum) {
-    __shared__ XyzzPacked<C> lds[64];
-    if (blockIdx.x >= *nheavy) return;
-    uint32_t g = heavy[blockIdx.x];
-    uint32_t t0 = task_off[g], nt = ntasks[g];
-    Xyzz<C> mine = xyzz_inf<C>();
-    for (uint32_t k = threadIdx.x; k < nt; k += 64) mine = xyzz_add(mine, xyzz_unpack(tsum[t0 + k]));
-    lds[threadIdx.x] = xyzz_pack(mine);
-    __syncthreads();
-    for (int s = 32; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s && threadIdx.x + s < nt) {
-            mine = xyzz_add(mine, xyzz_unpack(lds[threadIdx.x + s]));
-            lds[threadIdx.x] = xyzz_pack(mine);
-        }
+__global__ void __launch_bounds__(kBlock) k_combine_chunks(const uint2* __restrict__ chunks, const uint32_t* __restrict__ nchunks,
+                                                           const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks,
+                                                           XyzzPacked<C>* __restrict__ tsum) {
+    __shared__ XyzzPacked<C> lds[kBlock];
+    const uint32_t count = *nchunks;
+    for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+        const uint2 gc = chunks[c];
+        const uint32_t first = task_off[gc.x] + gc.y * kBlock, left = ntasks[gc.x] - gc.y * kBlock;
+        const uint32_t cnt = left < (uint32_t)kBlock ? left : (uint32_t)kBlock;
+        Xyzz<C> mine = threadIdx.x < cnt ? xyzz_unpack(tsum[first + threadIdx.x]) : xyzz_inf<C>();
+        mine = block_tree_sum<C>(mine, lds, (int)cnt);
+        if (threadIdx.x == 0) tsum[first] = xyzz_pack(mine);
+        __syncthreads();   // lds is reused by the next chunk
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_combine_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ nheavy,
+                                                          const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks,
+                                                          XyzzPacked<C>* __restrict__ tsum) {
+    __shared__ XyzzPacked<C> lds[kBlock];
+    const uint32_t count = *nheavy;
+    for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+        const uint32_t g = heavy[h];
+        const uint32_t t0 = task_off[g], nch = (ntasks[g] + kBlock - 1) / kBlock;
+        if (nch < 2) continue;   // a single chunk: k_combine_chunks already left the sum in tsum[t0] (uniform per block)
+        Xyzz<C> mine = xyzz_inf<C>();
+        for (uint32_t k = threadIdx.x; k < nch; k += kBlock) mine = xyzz_add(mine, xyzz_unpack(tsum[t0 + k * kBlock]));
+        __syncthreads();   // all chunk sums read before tsum[t0] is overwritten
+        mine = block_tree_sum<C>(mine, lds, nch < (uint32_t)kBlock ? (int)nch : kBlock);
+        if (threadIdx.x == 0) tsum[t0] = xyzz_pack(mine);
         __syncthreads();
     }
-    if (threadIdx.x == 0) tsum[t0] = xyzz_pack(mine);
 }
 
 // small * p by double-and-add (small < 2^16)
@@ -431,7 +457,7 @@ __device__ __forceinline__ Xyzz<C> xyzz_mul_small(uint32_t k, const Xyzz<C>& p) 
 // Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket indices t*m .. t*m + m - 1, and produces
 //   sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
 // Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
-template <class C>
+template <class C, bool FUSE>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t m,
                                                           XyzzPacked<C>* __restrict__ partial) {
@@ -448,7 +474,13 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
         uint32_t lo = t * m, hi = lo + m < B ? lo + m : B;
         for (uint32_t j = hi; j-- > lo;) {
             uint32_t g = tab.boff[w] + j;
-            if (ntasks[g]) run = xyzz_add(run, xyzz_unpack(tsum[task_off[g]]));
+            uint32_t nt = ntasks[g];
+            if (nt) {
+                // FUSE: a bucket cut into 2..kLightMax tasks is summed here (k_combine_light is then not launched);
+                // a heavy bucket was already folded into its first record by k_combine_heavy
+                uint32_t t0 = task_off[g], lim = (FUSE && nt <= kLightMax) ? nt : 1;
+                for (uint32_t k = 0; k < lim; k++) run = xyzz_add(run, xyzz_unpack(tsum[t0 + k]));
+            }
             tri = xyzz_add(tri, run);
         }
         mine = xyzz_add(tri, xyzz_mul_small<C>(lo, run));
