@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="also time the same MSMs with two in flight (extra field; off by default so that rocprofv3 averages of the default "
+                         "command are not mixed with concurrently running kernels)")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +126,7 @@ def main():
     # ---- extra (not `value`): the same K MSMs with two in flight (two contexts / HIP streams, one host thread).
     # The bucket reduce is latency-bound (one wave per SIMD), so a second MSM in flight fills the idle lanes.
     overlapped = None
-    if not use_dist:
+    if not use_dist and args.overlap:
         ctxs2 = [bp.Context(curve, local_rank) for _ in range(2)]
         views = [(bp.G1Vector.wrap_device(c, pts.device_ptr(), n), bp.FieldElementVector.wrap_device(c, sv.device_ptr(), n)) for c in ctxs2]
         for p2, s2 in views:
