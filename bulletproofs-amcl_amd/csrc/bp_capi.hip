@@ -35,6 +35,9 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
             c--;
         }
     }
+    // k_small_msm (n <= kSmallMsmMax): each lane multiplies by its digit, so narrow windows shorten the chain; below c = 4 the
+    // extra windows cost more on the host (one addition per window in the tail) than they save on the device
+    if (c_override <= 0 && n <= kSmallMsmMax && c > 4) c = 4;
     if (c < 2) c = 2;
     if (c > 16) c = 16;
     g.c = c;
@@ -125,6 +128,18 @@ struct Impl {
         if (n >= ((size_t)1 << 31)) return BP_ERR_ARG;                      // the sign lives in bit 31 of an index
         if ((uint64_t)W * n >= ((uint64_t)1 << 32)) return BP_ERR_ARG;      // 32-bit slot offsets
         hipStream_t st = ctx->stream;
+        static const bool small_path = getenv("BP_SMALL_MSM") ? atoi(getenv("BP_SMALL_MSM")) != 0 : true;
+        if (n <= kSmallMsmMax && small_path) {   // one launch: block per window, lane per term (k_small_msm)
+            int rc0;
+            if ((rc0 = ctx->window_sum.reserve((size_t)W * kXyzzBytes))) return rc0;
+            const bool tm0 = ctx->timing;
+            if (tm0) { if ((rc0 = ensure_events(ctx))) return rc0; for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st)); }
+            hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
+            BP_TRACE_SYNC(ctx, "k_small_msm<C>");
+            if (tm0) HIPCHK(hipEventRecord(ctx->ev[6], st));
+            HIPCHK(hipGetLastError());
+            return BP_OK;
+        }
         size_t nb = tab.nbuckets;
         size_t scan_blocks = (nb + kScanPerBlock - 1) / kScanPerBlock;
         // task length (see bp_kernels.cuh): >= 2x the mean bucket size when buckets are plentiful, else small enough

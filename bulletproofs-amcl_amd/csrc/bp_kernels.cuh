@@ -502,6 +502,46 @@ __global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __r
     if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
 }
 
+// ---------------------------------------------------------------------------------------------- small MSM (n <= kSmallMsmMax)
+constexpr size_t kSmallMsmMax = 512;   // above this the bucket pipeline wins (scripts/time_pair.py)
+// The bucket pipeline is a dozen dependent launches; for the 2n + 1 <= 256 terms of a small inner-product round most of its
+// time is launch gaps and the depth of the bucket reduce.  Here one block per window does the whole job in one launch: lane t
+// multiplies point t by its signed digit of this window (|digit| <= 2^(cw-1): a few doublings and mixed additions), then an LDS
+// tree adds the n products.  Same digit recoding and window table as the pipeline, so the host tail is unchanged.
+__device__ __forceinline__ uint32_t window_bits(const uint64_t (&q)[4], int off, int cw) {
+    const int word = off >> 6, sh = off & 63;
+    uint64_t lo = word == 0 ? q[0] : word == 1 ? q[1] : word == 2 ? q[2] : q[3];
+    uint64_t hi = word == 0 ? q[1] : word == 1 ? q[2] : word == 2 ? q[3] : 0;
+    uint64_t v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    return (uint32_t)v & ((1u << cw) - 1);
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __restrict__ pts, const ScalarWords* __restrict__ sc1,
+                                                      const ScalarWords* __restrict__ sc2, uint32_t n, WinTab tab,
+                                                      XyzzPacked<C>* __restrict__ window_sum) {
+    __shared__ XyzzPacked<C> lds[kBlock];
+    const int w = blockIdx.x, wps = tab.W / tab.nsets, set = w / wps;
+    const int cw = tab.cw[w], off = tab.off[w];
+    Xyzz<C> mine = xyzz_inf<C>();
+    for (uint32_t t = threadIdx.x; t < n; t += kBlock) {      // kSmallMsmMax / kBlock terms per lane at most
+        uint64_t q[4];
+        add256(q, (set ? sc2 : sc1)[t], tab.bias);
+        int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
+        if (d == 0) continue;
+        Aff<C> p = aff_unpack(pts[t]);
+        if (d < 0) { p.y = fe_neg(p.y); d = -d; }
+        Xyzz<C> acc = xyzz_from_aff(p);
+        for (int i = 30 - __clz(d); i >= 0; i--) {            // bits below the leading one
+            acc = xyzz_dbl(acc);
+            if ((d >> i) & 1) acc = xyzz_add_aff(acc, p);
+        }
+        mine = xyzz_add(mine, acc);
+    }
+    mine = block_tree_sum<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
+    if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
+}
+
 // ---------------------------------------------------------------------------------------------- device tail (optional)
 // sum_w 2^(off_w) S_w on the device: a strictly serial chain of ~bits doublings, executed by ONE lane.  Kept so that the
 // result can stay in HBM and to put a number on the design decision: ~2 ms here against ~0.13 ms for
