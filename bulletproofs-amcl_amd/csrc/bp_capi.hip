@@ -14,7 +14,6 @@ struct MsmGeom {
     int c;           // target window width
     WinTab tab;      // W windows of nearly equal width covering fr_bits + 1 bits
     uint32_t m;      // buckets per reduce thread
-    uint32_t bpw;    // reduce blocks per window (max over windows)
 };
 
 static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0) {
@@ -51,7 +50,7 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
     t.nsets = nsets;
     uint32_t bias[8] = {0};
     int off = 0;
-    uint32_t nb = 0, maxB = 0, rows = 0;
+    uint32_t nb = 0, rows = 0;
     for (int w = 0; w < W; w++) {
         const int w1 = w % W1;
         if (w1 == 0) off = 0;
@@ -65,7 +64,6 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
         rows += 1u << (cw - 1 - fb);
         uint32_t B = 1u << (cw - 1);
         nb += B;
-        if (B > maxB) maxB = B;
         if (w >= W1) { off += cw; continue; }     // the bias is per scalar: accumulate it over the first set only
         // bias += (2^(cw-1) - 1) << off
         uint64_t half1 = (uint64_t)B - 1;
@@ -100,8 +98,6 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
     uint32_t rb = 0;
     for (int w = 0; w < W; w++) { t.rboff[w] = (uint16_t)rb; uint32_t B = t.boff[w + 1] - t.boff[w]; rb += ((B + m - 1) / m + kBlock - 1) / kBlock; }
     t.rboff[W] = (uint16_t)rb;   // <= 256 by the choice of m unless m hit its cap (c = 16, two sets, m = 16: 256)
-    uint32_t T = (maxB + m - 1) / m;
-    g.bpw = (T + kBlock - 1) / kBlock;
 }
 
 // ------------------------------------------------------------------------------------------------ per-curve code
@@ -124,7 +120,7 @@ struct Impl {
         msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz);
         const WinTab& tab = g.tab;
         const int W = tab.W;
-        if (getenv("BP_TRACE")) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d nbuckets=%u m=%u bpw=%u\n", n, g.c, W, tab.nbuckets, g.m, g.bpw);
+        if (getenv("BP_TRACE")) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d nbuckets=%u m=%u reduce_blocks=%u\n", n, g.c, W, tab.nbuckets, g.m, (unsigned)tab.rboff[W]);
         if (n >= ((size_t)1 << 31)) return BP_ERR_ARG;                      // the sign lives in bit 31 of an index
         if ((uint64_t)W * n >= ((uint64_t)1 << 32)) return BP_ERR_ARG;      // 32-bit slot offsets
         hipStream_t st = ctx->stream;
@@ -243,13 +239,10 @@ struct Impl {
             else hipLaunchKernelGGL((k_accumulate<C, 3>), agrid, dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
         }
         if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
-        static const bool fuse = getenv("BP_FUSE_COMBINE") ? atoi(getenv("BP_FUSE_COMBINE")) != 0 : true;
-        if (!fuse) hipLaunchKernelGGL(k_combine_light<C>, dim3(bgrid), dim3(kBlock), 0, st, task_off, ntasks, (uint32_t)nb, tsum);
         hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(max_chunks < 1024 ? max_chunks : 1024)), dim3(kBlock), 0, st, chunks, nchunks, task_off, ntasks, tsum);
         hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)(max_heavy < 256 ? max_heavy : 256)), dim3(kBlock), 0, st, heavy, nheavy, task_off, ntasks, tsum);
         BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
-        if (fuse) hipLaunchKernelGGL((k_bucket_reduce<C, true>), dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
-        else hipLaunchKernelGGL((k_bucket_reduce<C, false>), dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tab.rboff[W]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tab, g.m, partial);
         BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
         hipLaunchKernelGGL(k_window_sums<C>, dim3(W), dim3(kBlock), 0, st, partial, tab, wsum);
         BP_TRACE_SYNC(ctx, "k_window_sums<C>");

@@ -17,10 +17,12 @@
 //   k_task_*         cut buckets into tasks of <= kTaskLen points, order tasks longest first
 //   k_accumulate     lane per task: XYZZ accumulator in VGPRs, gathers its points (96-B rows, 16-B vector loads) and
 //                    mixed-adds them
-//   k_combine_heavy  block per multi-task bucket: tree over its task sums
-//   k_bucket_reduce  thread per m consecutive buckets: running sum / sum of running sums, weighted by the
-//                    segment's base value, then an LDS tree per block            -> partial[]
+//   k_combine_chunks / k_combine_heavy   buckets cut into more than kLightMax tasks: block per 256-task chunk, then block
+//                    per bucket over its chunk sums (lighter multi-task buckets are summed inside k_bucket_reduce)
+//   k_bucket_reduce  compact grid of <= 256 blocks; thread per m consecutive buckets: running sum / sum of running sums,
+//                    weighted by the segment's base value, then an LDS tree per block            -> partial[]
 //   k_window_sums    block per window: tree over the partials                    -> window_sum[W]
+//   k_small_msm      n <= kSmallMsmMax terms: the whole device stage in one launch (block per window, lane per term)
 // The final  sum_w 2^(off_w) window_sum[w]  (a strictly serial chain of ~bits doublings) is folded on the host
 // (bp_capi.hip): one lane of a GPU would take ~2 ms for it, the host ~0.1 ms, and the result is needed on the
 // host anyway (it goes into the Fiat-Shamir transcript).
@@ -262,7 +264,7 @@ static __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in
 // is smaller, so that there are several times more tasks than lanes (otherwise the last, partly filled round of
 // waves costs up to half of the kernel).  Lengths are binned into <= 129 classes, longest first.
 constexpr uint32_t kTaskBins = 129;
-constexpr uint32_t kLightMax = 8;   // buckets of 2..kLightMax tasks are summed by one lane (k_combine_light), more by a wave
+constexpr uint32_t kLightMax = 8;   // buckets of 2..kLightMax tasks are summed inside k_bucket_reduce, heavier ones by k_combine_chunks / _heavy
 __device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = max(0, log2(L) - 7)
 
 // thread per bucket: ntasks[g], and a histogram of task lengths
@@ -382,20 +384,6 @@ __device__ __forceinline__ Xyzz<C> block_tree_sum(Xyzz<C> mine, XyzzPacked<C>* l
     return mine;
 }
 
-// Lane per bucket: buckets cut into 2..kLightMax tasks are summed sequentially -> tsum[task_off[g]].
-template <class C>
-__global__ void __launch_bounds__(kBlock) k_combine_light(const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks, uint32_t nbuckets,
-                                                          XyzzPacked<C>* __restrict__ tsum) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nbuckets) return;
-    uint32_t nt = ntasks[g];
-    if (nt < 2 || nt > kLightMax) return;
-    uint32_t t0 = task_off[g];
-    Xyzz<C> acc = xyzz_unpack(tsum[t0]);
-    for (uint32_t k = 1; k < nt; k++) acc = xyzz_add(acc, xyzz_unpack(tsum[t0 + k]));
-    tsum[t0] = xyzz_pack(acc);
-}
-
 // Heavy buckets (more than kLightMax tasks) are folded in two stages so that one bucket holding most of the points -- 0/1
 // scalars, the a_L / a_R commitments of a range proof, put half of all points into ONE bucket: 4096 task sums at n = 2^16 --
 // is a tree over many blocks instead of one long chain (one wave: 64 + 6 dependent additions, 1.23 ms; chunked: 8 + 1 + 4):
@@ -457,7 +445,7 @@ __device__ __forceinline__ Xyzz<C> xyzz_mul_small(uint32_t k, const Xyzz<C>& p) 
 // Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket indices t*m .. t*m + m - 1, and produces
 //   sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
 // Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
-template <class C, bool FUSE>
+template <class C>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t m,
                                                           XyzzPacked<C>* __restrict__ partial) {
@@ -476,9 +464,9 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
             uint32_t g = tab.boff[w] + j;
             uint32_t nt = ntasks[g];
             if (nt) {
-                // FUSE: a bucket cut into 2..kLightMax tasks is summed here (k_combine_light is then not launched);
-                // a heavy bucket was already folded into its first record by k_combine_heavy
-                uint32_t t0 = task_off[g], lim = (FUSE && nt <= kLightMax) ? nt : 1;
+                // a bucket cut into 2..kLightMax tasks is summed here (a separate lane-per-bucket kernel for it cost 0.1-0.2 ms
+                // at n = 2^16); a heavier bucket was already folded into its first record by k_combine_chunks / _heavy
+                uint32_t t0 = task_off[g], lim = nt <= kLightMax ? nt : 1;
                 for (uint32_t k = 0; k < lim; k++) run = xyzz_add(run, xyzz_unpack(tsum[t0 + k]));
             }
             tri = xyzz_add(tri, run);
