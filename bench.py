@@ -200,6 +200,13 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_note,
                         "kernel_ms": round(avg * 1e3, 4), "algorithmic_bytes_per_launch": n * unit_bytes,
                         "pipeline_GBs": round(n * unit_bytes / (float(np.mean(dev_ms)) * 1e-3) / 1e9, 2)}
+            # The kernel is ALU-bound (VALU ~91 % busy, profiles/r01_bench_n1_pmc_sq.json), so the HBM fraction above says
+            # little about it; beside it, the field-multiplication rate against the microbenchmarked ceiling of the same
+            # multiplier (microbench/fpmul_rate.hip, formulation C at 8 waves/SIMD).  One mixed addition = 8M + 2S.
+            if args.curve == "bls12_381":
+                fpmul = n * int(W) * 10 / avg
+                roofline["alu"] = {"achieved": round(fpmul, 0), "peak": 6.6e10, "unit": "381-bit Fp-mul/s", "frac": round(fpmul / 6.6e10, 4),
+                                   "how": "n * windows mixed additions * 10 products each / kernel time; peak = microbench/fpmul_rate.hip"}
         out = {
             "metric": "BLS12-381 G1 scalar-muls/s at n=2^20 MSM" if (args.curve == "bls12_381" and args.lg_n == 20) else
                       "%s G1 scalar-muls/s at n=2^%d MSM" % (args.curve, args.lg_n),
