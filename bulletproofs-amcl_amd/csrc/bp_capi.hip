@@ -348,9 +348,15 @@ struct Impl {
         // the two serial tails (~0.12 ms each: 255 dependent doublings) are independent: fold the second on another thread
         const host::Tail<C>& tl = tail();
         const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
-        std::thread second([&]() { tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le); });
+        bool spawned = false;
+        std::thread second;
+        try {
+            second = std::thread([&]() { tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le); });
+            spawned = true;
+        } catch (...) {}   // no thread available: fold both here (an exception must not cross the C ABI)
         tl.fold(rec, 1, W1, g.tab.cw, out1_le);
-        second.join();
+        if (spawned) second.join();
+        else tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le);
         return BP_OK;
     }
 

@@ -189,12 +189,12 @@ def test_msm_full_size_linearity(bp, ctxs, name, lg):
     pts.free()
 
 
+@pytest.mark.parametrize("n", [6000, 600, 2])     # 600 -> two shards of 300 terms: the single-launch small-MSM path
 @pytest.mark.parametrize("name", CURVES)
-def test_two_stage_sharded_msm(bp, ctxs, name):
+def test_two_stage_sharded_msm(bp, ctxs, name, n):
     """The multi-GPU decomposition on one GPU: two index-range shards -> window records -> one finish."""
     import torch
     ctx = ctxs[name]
-    n = 6000
     ks = O.random_scalars(ctx.curve, 41, n)
     ss = O.random_scalars(ctx.curve, 42, n)
     pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
