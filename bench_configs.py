@@ -110,9 +110,42 @@ def cfg3():
     sv = bp.FieldElementVector.from_bytes(ctx, sb, m)
     t, got = best_of(lambda: Pv.multi_scalar_mul_var_time(sv))
     want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, pk, sb, m), O.generator(ctx.curve))
+    vmsm = {"terms": m, "ms": t * 1e3, "ok": bool(got == want)}
+    # flattened_constraints at the config's size (136 192 constraints, 65 536 gates, m = 3 072): a synthetic
+    # system of that shape (3 wire terms, every 4th constraint a committed term, every 8th a constant), checked against the
+    # Python-int restatement of src/r1cs/verifier.rs:149-193
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyref as R
+    nq, mV = 136192, 3072
+    crng = np.random.default_rng(11)
+    kinds = crng.integers(0, 3, size=(nq, 3))
+    idxs = crng.integers(0, n, size=(nq, 3))
+    small = crng.integers(1, 1 << 30, size=(nq, 5))
+    cons, terms = [], []
+    for q in range(nq):
+        ts = [(int(kinds[q, j]), int(idxs[q, j]), int(small[q, j])) for j in range(3)]
+        if q % 4 == 0:
+            ts.append((3, q % mV, int(small[q, 3])))
+        if q % 8 == 0:
+            ts.append((4, 0, int(small[q, 4])))
+        cons.append(ts)
+        terms += [(q, k, i, c) for k, i, c in ts]
+    t0 = time.perf_counter()
+    plan = bp.R1CSPlan(ctx, terms, nq, n, mV)
+    t_plan = time.perf_counter() - t0
+    zb = random_scalars(ctx.r, info.fr_bits, 1, 340)
+    tf, outs = best_of(lambda: plan.flattened_constraints(zb))
+    t0 = time.perf_counter()
+    exp = R.r1cs_flattened_constraints(R.BLS12_381, cons, int.from_bytes(zb, "little"), n, mV)
+    t_py = time.perf_counter() - t0
+    to_ints = lambda v: [int.from_bytes(v[i:i + 32], "little") for i in range(0, len(v), 32)]
+    flat_ok = all(to_ints(outs[k].to_bytes()) == exp[k] for k in range(4)) and int.from_bytes(outs[4], "little") == exp[4]
+    flatten = {"constraints": nq, "terms": len(terms), "ms": tf * 1e3, "plan_build_ms_once_per_circuit": t_plan * 1e3, "ok": bool(flat_ok),
+               "python_int_restatement_ms": t_py * 1e3}
+    plan.free()
     ctx.close()
     return {"config": "cfg3 (hot-path shape): 5 commitment MSMs at 2^16 + IPP 2^16 + verifier MSM of 134189 terms, BLS12-381",
-            "commitment_msms": msms, "ipp": ipp, "verifier_msm": {"terms": m, "ms": t * 1e3, "ok": bool(got == want)},
+            "commitment_msms": msms, "ipp": ipp, "verifier_msm": vmsm, "flattened_constraints": flatten,
             "prover_hot_path_ms": sum(v["ms"] for v in msms.values()) + ipp["create_ms"]}
 
 

@@ -107,6 +107,9 @@ SYMBOLS = {
     "bp_vecpoly3_special_inner_product": (_I, [_P, _PP, _PP, _U8P]),
     "bp_vecpoly1_inner_product": (_I, [_P, _PP, _PP, _U8P]),
     "bp_vecpoly_eval": (_I, [_P, _PP, _I, _U8P, _PP]),
+    "bp_r1cs_plan_create": (_I, [_P, _SZ, _P, _U8P, _P, _U8P, _SZ, _SZ, _SZ, _PP]),
+    "bp_r1cs_plan_free": (_I, [_P]),
+    "bp_r1cs_flattened_constraints": (_I, [_P, _P, _U8P, _PP, _U8P]),
     "bp_r1cs_prover_polys": (_I, [_P, _PP, _U8P, _PP]),
     "bp_r1cs_ipp_inputs": (_I, [_P, _P, _P, _U8P, _U8P, _SZ, _SZ, _PP]),
     "bp_r1cs_verifier_scalars": (_I, [_P, _P, _U8P, _U8P, _SZ, _SZ, _SZ, _P, _P, _P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _PP, _PP]),
@@ -654,6 +657,45 @@ class VecPoly3:
 
 
 # ---- R1CS vector pipeline (src/r1cs/prover.rs:458-563, src/r1cs/verifier.rs:342-390) --------------------------------
+
+VAR_MUL_LEFT, VAR_MUL_RIGHT, VAR_MUL_OUTPUT, VAR_COMMITTED, VAR_ONE = 0, 1, 2, 3, 4
+
+
+class R1CSPlan:
+    """The terms of a constraint system regrouped once for `flattened_constraints` (src/r1cs/prover.rs:142-184,
+    src/r1cs/verifier.rs:149-193).  terms: iterable of (constraint q, kind VAR_*, index, coeff as int or 32-byte LE)."""
+
+    def __init__(self, ctx, terms, n_constraints, n, m):
+        terms = list(terms)
+        T = len(terms)
+        tq = (ctypes.c_uint32 * max(1, T))(*[t[0] for t in terms])
+        kind = bytes(t[1] for t in terms)
+        idx = (ctypes.c_uint32 * max(1, T))(*[t[2] for t in terms])
+        coeff = b"".join(t[3] if isinstance(t[3], (bytes, bytearray)) else (t[3] % ctx.r).to_bytes(32, "little") for t in terms)
+        h = ctypes.c_void_p()
+        _check(lib().bp_r1cs_plan_create(ctx.h, T, ctypes.cast(tq, ctypes.c_void_p), kind or b"\0", ctypes.cast(idx, ctypes.c_void_p), coeff or b"\0",
+                                         n_constraints, n, m, ctypes.byref(h)), "bp_r1cs_plan_create")
+        self.ctx, self.h, self.n, self.m = ctx, h, n, m
+
+    def flattened_constraints(self, z_le32, want_constant=True):
+        """-> (wL, wR, wO, wV, wc): four FieldElementVectors and the 32-byte constant (None for the prover's form)."""
+        out = (ctypes.c_void_p * 4)()
+        wc = ctypes.create_string_buffer(32) if want_constant else None
+        _check(lib().bp_r1cs_flattened_constraints(self.ctx.h, self.h, bytes(z_le32), out, wc), "bp_r1cs_flattened_constraints")
+        vs = [FieldElementVector(self.ctx, ctypes.c_void_p(out[k])) for k in range(4)]
+        return vs[0], vs[1], vs[2], vs[3], (wc.raw if wc is not None else None)
+
+    def free(self):
+        if self.h:
+            lib().bp_r1cs_plan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 def r1cs_prover_polys(ctx, a_L, a_R, a_O, s_L, s_R, wL, wR, wO, y_le32):
     """-> (l_poly, r_poly) as VecPoly3 with the structurally-zero vectors filled by zeros"""

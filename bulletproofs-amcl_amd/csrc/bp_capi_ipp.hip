@@ -31,9 +31,17 @@ struct bp_ipp_state {
     int device;
 };
 
+// flattened_constraints plan: the circuit's terms grouped by destination (CSR), resident on the device
+struct bp_r1cs_plan {
+    int device, curve;
+    size_t n, m, nq, nterms, ndest, nheavy;
+    void *seg, *tq, *coeff, *heavy;     // uint32[ndest + 1], uint32[nterms], ScalarWords[nterms], uint32[nheavy]
+};
+
 namespace {
 
 constexpr unsigned kInnerBlocks = 256;
+constexpr uint32_t kFlattenLightMax = 64;   // destinations with more terms get a block (k_r1cs_flatten_heavy)
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
@@ -414,6 +422,36 @@ static int r1cs_verifier_scalars_impl(bp_ctx* ctx, Transcript& t, const uint8_t*
 
 }  // namespace
 
+template <class C>
+static int flattened_constraints_impl(bp_ctx* ctx, const bp_r1cs_plan* p, const uint8_t* z_le32, bp_frvec* outv[4], uint8_t* wc_le32) {
+    using F = typename C::Fr;
+    void *zp = nullptr, *all = nullptr;
+    auto cleanup = [&]() { if (zp) (void)hipFree(zp); if (all) (void)hipFree(all); };
+    if (hipMalloc(&zp, (p->nq ? p->nq : 1) * 32) != hipSuccess || hipMalloc(&all, p->ndest * 32) != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+    hipStream_t s = ctx->stream;
+    if (p->nq) hipLaunchKernelGGL(k_fr_powers_mont<C>, dim3(blocks_for(p->nq)), dim3(kBlock), 0, s, fr_mont_words<F>(fr_from_le<F>(z_le32)), p->nq, (ScalarWords*)zp);
+    hipLaunchKernelGGL(k_r1cs_flatten<C>, dim3(blocks_for(p->ndest)), dim3(kBlock), 0, s, (const uint32_t*)p->seg, (const uint32_t*)p->tq,
+                       (const ScalarWords*)p->coeff, (const ScalarWords*)zp, (uint32_t)(3 * p->n), (uint32_t)p->ndest, kFlattenLightMax, (ScalarWords*)all);
+    if (p->nheavy)
+        hipLaunchKernelGGL(k_r1cs_flatten_heavy<C>, dim3((unsigned)(p->nheavy < 1024 ? p->nheavy : 1024)), dim3(kBlock), 0, s, (const uint32_t*)p->heavy,
+                           (uint32_t)p->nheavy, (const uint32_t*)p->seg, (const uint32_t*)p->tq, (const ScalarWords*)p->coeff, (const ScalarWords*)zp,
+                           (uint32_t)(3 * p->n), (ScalarWords*)all);
+    if (hipGetLastError() != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+    const size_t lens[4] = {p->n, p->n, p->n, p->m}, offs[4] = {0, p->n, 2 * p->n, 3 * p->n};
+    int rc = BP_OK;
+    for (int k = 0; k < 4 && rc == BP_OK; k++) {
+        rc = bp_frvec_alloc(ctx, lens[k], &outv[k]);
+        if (rc == BP_OK && lens[k] &&
+            hipMemcpyAsync(outv[k]->d, (const uint8_t*)all + offs[k] * 32, lens[k] * 32, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            rc = BP_ERR_DEVICE;
+    }
+    if (rc == BP_OK && wc_le32 && hipMemcpyAsync(wc_le32, (const uint8_t*)all + (p->ndest - 1) * 32, 32, hipMemcpyDeviceToHost, s) != hipSuccess) rc = BP_ERR_DEVICE;
+    if (hipStreamSynchronize(s) != hipSuccess && rc == BP_OK) rc = BP_ERR_DEVICE;
+    cleanup();
+    if (rc) for (int k = 0; k < 4; k++) { bp_frvec_free(outv[k]); outv[k] = nullptr; }
+    return rc;
+}
+
 extern "C" {
 
 // ---- transcript ---------------------------------------------------------------------------------------------
@@ -785,6 +823,67 @@ int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_fa
     if (m == 0) return BP_OK;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     IPP_DISPATCH(ctx->curve, I::verify_batch(ctx, n, lg_n, G_factors, H_factors, G, H, proofs, m, weights_le32));
+}
+
+int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                        const uint8_t* coeff_le32, size_t n_constraints, size_t n, size_t m, bp_r1cs_plan** out) {
+    if (!ctx || !out || (n_terms && (!term_constraint || !term_kind || !term_index || !coeff_le32))) return BP_ERR_ARG;
+    *out = nullptr;
+    if (n_terms >= ((size_t)1 << 32) || 3 * n + m + 1 >= ((size_t)1 << 32) || n_constraints >= ((size_t)1 << 32)) return BP_ERR_ARG;
+    const size_t ndest = 3 * n + m + 1;
+    std::vector<uint32_t> dest(n_terms), seg(ndest + 1, 0);
+    for (size_t t = 0; t < n_terms; t++) {
+        const uint8_t k = term_kind[t];
+        const uint32_t i = term_index[t];
+        if (term_constraint[t] >= n_constraints) return BP_ERR_ARG;
+        if (k <= BP_VAR_MUL_OUTPUT) { if (i >= n) return BP_ERR_ARG; dest[t] = (uint32_t)(k * n + i); }
+        else if (k == BP_VAR_COMMITTED) { if (i >= m) return BP_ERR_ARG; dest[t] = (uint32_t)(3 * n + i); }
+        else if (k == BP_VAR_ONE) dest[t] = (uint32_t)(3 * n + m);
+        else return BP_ERR_ARG;
+        seg[dest[t] + 1]++;
+    }
+    for (size_t d = 0; d < ndest; d++) seg[d + 1] += seg[d];
+    std::vector<uint32_t> cur(seg.begin(), seg.end() - 1), tq(n_terms ? n_terms : 1), heavy;
+    std::vector<uint8_t> coeff((n_terms ? n_terms : 1) * 32);
+    for (size_t t = 0; t < n_terms; t++) {                 // counting sort by destination (order inside one is irrelevant)
+        const uint32_t pos = cur[dest[t]]++;
+        tq[pos] = term_constraint[t];
+        memcpy(&coeff[(size_t)pos * 32], coeff_le32 + 32 * t, 32);
+    }
+    for (size_t d = 0; d < ndest; d++) if (seg[d + 1] - seg[d] > kFlattenLightMax) heavy.push_back((uint32_t)d);
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    bp_r1cs_plan* p = new (std::nothrow) bp_r1cs_plan{ctx->device, ctx->curve, n, m, n_constraints, n_terms, ndest, heavy.size(), nullptr, nullptr, nullptr, nullptr};
+    if (!p) return BP_ERR_DEVICE;
+    auto fail = [&]() { bp_r1cs_plan_free(p); return BP_ERR_DEVICE; };
+    if (hipMalloc(&p->seg, (ndest + 1) * 4) != hipSuccess || hipMalloc(&p->tq, tq.size() * 4) != hipSuccess ||
+        hipMalloc(&p->coeff, coeff.size()) != hipSuccess || hipMalloc(&p->heavy, (heavy.size() ? heavy.size() : 1) * 4) != hipSuccess)
+        return fail();
+    hipStream_t s = ctx->stream;
+    if (hipMemcpyAsync(p->seg, seg.data(), (ndest + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(p->tq, tq.data(), tq.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(p->coeff, coeff.data(), coeff.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+        (heavy.size() && hipMemcpyAsync(p->heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return fail();
+    *out = p;
+    return BP_OK;
+}
+
+int bp_r1cs_plan_free(bp_r1cs_plan* p) {
+    if (!p) return BP_OK;
+    (void)hipSetDevice(p->device);
+    for (void* b : {p->seg, p->tq, p->coeff, p->heavy}) if (b) (void)hipFree(b);
+    delete p;
+    return BP_OK;
+}
+
+int bp_r1cs_flattened_constraints(bp_ctx* ctx, const bp_r1cs_plan* plan, const uint8_t* z_le32, bp_frvec* out[4], uint8_t* wc_le32) {
+    if (!ctx || !plan || !z_le32 || !out) return BP_ERR_ARG;
+    for (int k = 0; k < 4; k++) out[k] = nullptr;
+    if (plan->curve != ctx->curve || plan->device != ctx->device) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    if (ctx->curve == BP_CURVE_BLS12_381) return flattened_constraints_impl<Bls381>(ctx, plan, z_le32, out, wc_le32);
+    return flattened_constraints_impl<Bn254>(ctx, plan, z_le32, out, wc_le32);
 }
 
 // IPP::verification_scalars (ipp.rs:262-315): (u_j^2, u_j^-2, s) as canonical LE scalars; host arithmetic.

@@ -276,6 +276,53 @@ __global__ void __launch_bounds__(kBlock) k_r1cs_verifier_scalars(const ScalarWo
     fr_store<F>(h_sc, i, fe_from_mont<F>(h));
 }
 
+// ---------------------------------------------------------------------------------------------- flattened constraints
+// Prover::flattened_constraints / Verifier::flattened_constraints (/root/reference src/r1cs/prover.rs:142-184,
+// src/r1cs/verifier.rs:149-193): for every term (variable, coeff) of constraint q,  w_kind[index] += z^(q+1) coeff  (wV and
+// the constant wc are subtracted).  The reference walks the constraints in order; the sums are order-independent, so the
+// terms are regrouped ONCE per circuit by destination (plan: CSR over destinations d = kind * n + index | 3n + index | 3n + m)
+// and each proof evaluates  out[d] = +- sum_t zp[q_t] coeff_t  with zp[q] = z^(q+1).
+//   k_fr_powers_mont      zp[q] = z^(q+1), Montgomery form
+//   k_r1cs_flatten        lane per destination with at most `light_max` terms
+//   k_r1cs_flatten_heavy  block per destination with more (the constant term collects one term per constraint that has one)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_powers_mont(ScalarWords z_mont, size_t nq, ScalarWords* __restrict__ zp) {
+    using F = typename C::Fr;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    fr_store<F>(zp, q, fr_pow_index<F>(fe_unpack_words<F>(z_mont.w), q + 1));
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_r1cs_flatten(const uint32_t* __restrict__ seg, const uint32_t* __restrict__ tq,
+                                                         const ScalarWords* __restrict__ coeff, const ScalarWords* __restrict__ zp, uint32_t n3,
+                                                         uint32_t ndest, uint32_t light_max, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= ndest) return;
+    const uint32_t lo = seg[d], hi = seg[d + 1];
+    if (hi - lo > light_max) return;                       // k_r1cs_flatten_heavy
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t t = lo; t < hi; t++) acc = fe_add(acc, fe_mul(fr_load<F>(zp, tq[t]), fr_load<F>(coeff, t)));   // Montgomery x canonical
+    fr_store<F>(out, d, d >= n3 ? fe_neg(acc) : acc);
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_r1cs_flatten_heavy(const uint32_t* __restrict__ heavy, uint32_t nheavy, const uint32_t* __restrict__ seg,
+                                                               const uint32_t* __restrict__ tq, const ScalarWords* __restrict__ coeff,
+                                                               const ScalarWords* __restrict__ zp, uint32_t n3, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t d = heavy[h], lo = seg[d], hi = seg[d + 1];
+        Fe<F> acc = fe_zero<F>();
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += kBlock) acc = fe_add(acc, fe_mul(fr_load<F>(zp, tq[t]), fr_load<F>(coeff, t)));
+        acc = block_fr_sum<F>(acc, lds);
+        if (threadIdx.x == 0) fr_store<F>(out, d, d >= n3 ? fe_neg(acc) : acc);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- IPP round
 // Assemble the MSM terms of L and R for the current round of length n = 2h (src/ipp.rs:80-104 / :148-170):
 //   L: points [G_R | H_L | Q], scalars [a_L (.Gf_R) | b_R (.Hf_L) | c_L]

@@ -255,6 +255,18 @@ int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L
                                 uint8_t* u_inv_sq, uint8_t* s);
 
 /* ---- R1CS vector pipeline either side of the IPP ---------------------------------------------- */
+/* flattened_constraints (src/r1cs/prover.rs:142-184; src/r1cs/verifier.rs:149-193): wL, wR, wO (length n), wV (length
+ * m) and the constant wc = sums of z^(q+1) * coeff over the terms of constraint q (wV and wc subtracted).  The constraint
+ * system is fixed per circuit, so its terms are regrouped once into a plan; each proof evaluates the plan for its z.
+ * Term t: constraint term_constraint[t] (0-based, any order), variable kind term_kind[t], index term_index[t] (< n for
+ * the multiplier kinds, < m for BP_VAR_COMMITTED, ignored for BP_VAR_ONE), coefficient coeff_le32 + 32 t. */
+enum { BP_VAR_MUL_LEFT = 0, BP_VAR_MUL_RIGHT = 1, BP_VAR_MUL_OUTPUT = 2, BP_VAR_COMMITTED = 3, BP_VAR_ONE = 4 };
+typedef struct bp_r1cs_plan bp_r1cs_plan;
+int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                        const uint8_t* coeff_le32, size_t n_constraints, size_t n, size_t m, bp_r1cs_plan** out);
+int bp_r1cs_plan_free(bp_r1cs_plan* plan);
+/* out = {wL, wR, wO, wV} (new vectors); wc_le32 may be NULL (the prover does not need the constant, prover.rs:176-178). */
+int bp_r1cs_flattened_constraints(bp_ctx* ctx, const bp_r1cs_plan* plan, const uint8_t* z_le32, bp_frvec* out[4], uint8_t* wc_le32);
 /* Prover, src/r1cs/prover.rs:465-486.  in = {a_L, a_R, a_O, s_L, s_R, wL, wR, wO} (equal lengths n; wL.. are the
  * flattened constraints, computed on the host); out = {l1, l2, l3, r0, r1, r3}: the non-zero coefficient vectors of
  * l(X) = l1 X + l2 X^2 + l3 X^3 and r(X) = r0 + r1 X + r3 X^3 (feed bp_vecpoly3_special_inner_product / bp_vecpoly_eval). */

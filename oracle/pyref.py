@@ -420,6 +420,30 @@ def ipp_verify(curve, n, transcript, Gf, Hf, P, Q, G, H, a, b, Lv, Rv):
 # --------------------------------------------------------------------------- deterministic inputs
 
 
+def r1cs_flattened_constraints(curve, constraints, z, n, m):
+    """Verifier::flattened_constraints (src/r1cs/verifier.rs:149-193; the prover's form, src/r1cs/prover.rs:142-184, is the
+    same without wc).  constraints: list of term lists [(kind, index, coeff)], kind 0/1/2 = MultiplierLeft/Right/Output,
+    3 = Committed, 4 = One.  Walks the constraints in the reference's order with exp_z = z, z^2, ..."""
+    r = curve.r
+    wL, wR, wO, wV, wc = [0] * n, [0] * n, [0] * n, [0] * m, 0
+    exp_z = z % r
+    for terms in constraints:
+        for kind, i, coeff in terms:
+            v = exp_z * coeff % r
+            if kind == 0:
+                wL[i] = (wL[i] + v) % r
+            elif kind == 1:
+                wR[i] = (wR[i] + v) % r
+            elif kind == 2:
+                wO[i] = (wO[i] + v) % r
+            elif kind == 3:
+                wV[i] = (wV[i] - v) % r
+            else:
+                wc = (wc - v) % r
+        exp_z = exp_z * z % r
+    return wL, wR, wO, wV, wc
+
+
 class SplitMix64:
     """Seeded generator shared (by construction) with oracle/rng.h and the host library."""
 

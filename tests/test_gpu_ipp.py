@@ -326,3 +326,70 @@ def test_ipp_verify_batch(bp, ctxs, name, n, unit_gf, m):
             bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, refs(mut))
     with pytest.raises(bp.VerificationError):                                          # wrong n for these proofs
         bp.IPP.verify_batch(ctx, 2 * n, Gf, Hf, Gv, Hv, refs())
+
+
+def _random_constraint_system(rng, r, nq, n, m, hub=None):
+    """nq linear combinations of 0..6 terms each over MultiplierLeft/Right/Output(i < n), Committed(i < m) and One();
+    `hub` = a variable that appears in most constraints (a destination with hundreds of terms)."""
+    cons = []
+    for q in range(nq):
+        terms = []
+        for _ in range(rng.randrange(7)):
+            kind = rng.choice([0, 0, 1, 1, 2, 3, 4])
+            idx = rng.randrange(n) if kind <= 2 else (rng.randrange(m) if kind == 3 else 0)
+            coeff = rng.choice([1, r - 1, 2, rng.randrange(r), rng.randrange(r), 0])
+            terms.append((kind, idx, coeff))
+        if hub is not None and rng.random() < 0.8:
+            terms.append((hub[0], hub[1], rng.randrange(r)))
+        cons.append(terms)
+    return cons
+
+
+@pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("nq,n,m", [(0, 4, 1), (1, 1, 1), (37, 5, 3), (700, 64, 8), (5000, 300, 0)])
+def test_r1cs_flattened_constraints(bp, ctxs, name, nq, n, m):
+    """Prover/Verifier::flattened_constraints (src/r1cs/prover.rs:142-184, verifier.rs:149-193) against the Python-int
+    restatement that walks the constraints in the reference's order; includes destinations with hundreds of terms (the
+    block-per-destination kernel) and constraints with no terms at all."""
+    import random
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    ctx = ctxs[name]
+    r = ctx.r
+    curve = R.CURVES[name]
+    rng = random.Random(1000 * nq + n)
+    cons = _random_constraint_system(rng, r, nq, n, max(m, 1) if m else 1, hub=(1, n // 2) if nq >= 100 else None)
+    if m == 0:   # no committed variables: drop those terms
+        cons = [[t for t in terms if t[0] != 3] for terms in cons]
+    terms = [(q, kind, idx, coeff) for q, ts in enumerate(cons) for kind, idx, coeff in ts]
+    rng.shuffle(terms)                                     # the plan does not depend on the order the terms arrive in
+    plan = bp.R1CSPlan(ctx, terms, nq, n, m)
+    for z in (rng.randrange(1, r), 1, 0):
+        wL, wR, wO, wV, wc = plan.flattened_constraints(z.to_bytes(32, "little"))
+        eL, eR, eO, eV, ec = R.r1cs_flattened_constraints(curve, cons, z, n, m)
+        assert ints(wL.to_bytes()) == eL and ints(wR.to_bytes()) == eR and ints(wO.to_bytes()) == eO
+        assert ints(wV.to_bytes()) == eV and int.from_bytes(wc, "little") == ec
+        assert plan.flattened_constraints(z.to_bytes(32, "little"), want_constant=False)[4] is None
+    plan.free()
+
+
+def test_r1cs_plan_argument_checks(bp, ctxs):
+    ctx = ctxs["bls12_381"]
+    for bad in ([(5, 0, 0, 1)],            # constraint index out of range
+                [(0, 0, 9, 1)],            # multiplier index >= n
+                [(0, 3, 2, 1)],            # committed index >= m
+                [(0, 7, 0, 1)]):           # unknown variable kind
+        with pytest.raises(bp.ArgError):
+            bp.R1CSPlan(ctx, bad, 5, 4, 2)
+    plan = bp.R1CSPlan(ctx, [(0, 4, 0, 3)], 1, 4, 2)       # a lone constant term
+    other = bp.Context(bp.BN254, 0)
+    with pytest.raises(bp.ArgError):                        # a plan belongs to its curve
+        import ctypes
+        out = (ctypes.c_void_p * 4)()
+        rc = bp.lib().bp_r1cs_flattened_constraints(other.h, plan.h, (1).to_bytes(32, "little"), out, None)
+        if rc == bp.BP_ERR_ARG:
+            raise bp.ArgError("bp_r1cs_flattened_constraints failed with status 2")
+    other.close()
+    wL, wR, wO, wV, wc = plan.flattened_constraints((5).to_bytes(32, "little"))
+    assert int.from_bytes(wc, "little") == (ctx.r - 15) and ints(wL.to_bytes()) == [0] * 4
