@@ -164,6 +164,95 @@ def cfg5():
     return {"config": "cfg5: BN254 (AMCL/Nogami) 2^20 MSM + IPP n=2^12", "msm_ms": t * 1e3, "msm_scalar_muls_per_s": n / t, "msm_ok": bool(got == want), "ipp": ipp}
 
 
+def bound_check_chain(r, checks, bits, rng):
+    """The circuit of BASELINE config 3: `checks` bound checks (src/r1cs/gadgets/bound_check.rs:12-40) of `bits`-bit numbers,
+    each = 3 committed values (v, a = v - min, b = max - v), 3 linear constraints and two positive_no gadgets
+    (helper_constraints/positive_no.rs:8-42: per bit one multiplier (1 - bit, bit, 0), `o = 0`, `a + b - 1 = 0`, and
+    `-x + sum 2^i b_i = 0`).  1024 checks of 32 bits: 65 536 gates, 136 192 constraints, m = 3 072.
+    Returns (terms, n_constraints, aL, aR, aO, v) with terms = (constraint, kind, index, coeff)."""
+    L, R_, O_, C, ONE = 0, 1, 2, 3, 4
+    terms, aL, aR, v = [], [], [], []
+    q = 0
+    for c in range(checks):
+        lo = int(rng.integers(0, 1 << 20))
+        hi = lo + (1 << bits) - 1 - int(rng.integers(0, 1 << 10))
+        val = int(rng.integers(lo, hi + 1))
+        a, b = val - lo, hi - val
+        iv, ia, ib = 3 * c, 3 * c + 1, 3 * c + 2
+        v += [val, a, b]
+        terms += [(q, C, iv, 1), (q, ONE, 0, (-lo) % r), (q, C, ia, r - 1)]; q += 1                 # v - min - a = 0
+        terms += [(q, ONE, 0, hi), (q, C, iv, r - 1), (q, C, ib, r - 1)]; q += 1                    # max - v - b = 0
+        terms += [(q, C, ia, 1), (q, C, ib, 1), (q, ONE, 0, (-(hi - lo)) % r)]; q += 1              # a + b = max - min
+        for x, ix in ((a, ia), (b, ib)):
+            final = [(C, ix, r - 1)]
+            for i in range(bits):
+                g = len(aL)
+                bit = (x >> i) & 1
+                aL.append(1 - bit); aR.append(bit)
+                terms.append((q, O_, g, 1)); q += 1                                                  # o = 0
+                terms += [(q, L, g, 1), (q, R_, g, 1), (q, ONE, 0, r - 1)]; q += 1                   # a + b - 1 = 0
+                final.append((R_, g, (1 << i) % r))
+            terms += [(q, k, i2, cf) for k, i2, cf in final]; q += 1                                 # -x + sum 2^i b_i = 0
+    return terms, q, aL, aR, [0] * len(aL), v
+
+
+def cfg3_e2e():
+    """BASELINE config 3 end to end: R1CS proof of 1024 chained 32-bit bound checks (2^16 multiplication gates), created and
+    verified through bulletproofs-amcl_amd/r1cs.py -- the host-side mirror of Prover::prove / Verifier::verify over the C ABI.
+    Untimed setup: generators (get_generators), the per-circuit constraint plan, the witness upload and the 3 072 Pedersen
+    commitments V of the statement; timed: everything from the first transcript operation to the proof / the verdict."""
+    from bulletproofs_amcl_amd import r1cs as R1
+    ctx = bp.Context(bp.BLS12_381, 0)
+    info = bp.curve_info(ctx.curve)
+    r = ctx.r
+    rng = np.random.default_rng(2024)
+    t0 = time.perf_counter()
+    terms, nq, aL, aR, aO, v = bound_check_chain(r, 1024, 32, rng)
+    n, m = len(aL), len(v)
+    t_circ = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gens = R1.Generators(ctx, n)
+    t_gens = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    plan = bp.R1CSPlan(ctx, terms, nq, n, m)
+    t_plan = time.perf_counter() - t0
+    small = lambda xs: bp.FieldElementVector.from_bytes(ctx, b"".join(int(x).to_bytes(32, "little") for x in xs), len(xs))
+    dAL, dAR, dAO = small(aL), small(aR), small(aO)
+    vb = [int.from_bytes(random_scalars(r, info.fr_bits, 1, 9000 + j), "little") for j in range(m)]
+    dVB = small(vb)
+    t0 = time.perf_counter()
+    V = [gens.commit(v[j], vb[j]) for j in range(m)]
+    t_commit = time.perf_counter() - t0
+    sL = bp.FieldElementVector.from_bytes(ctx, random_scalars(r, info.fr_bits, n, 9100), n)
+    sR = bp.FieldElementVector.from_bytes(ctx, random_scalars(r, info.fr_bits, n, 9101), n)
+    bl = {k: int.from_bytes(random_scalars(r, info.fr_bits, 1, 9200 + i), "little") for i, k in enumerate(("i", "o", "s", "t1", "t3", "t4", "t5", "t6"))}
+
+    def do_prove():
+        return R1.prove(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), dAL, dAR, dAO, dVB, sL, sR, bl)
+
+    def do_verify(proof):
+        return R1.verify(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), V, proof)
+
+    t0 = time.perf_counter()
+    R1.start_transcript(ctx, b"cfg3", V)
+    t_tr = time.perf_counter() - t0
+    proof = do_prove()
+    tp, proof = best_of(do_prove, reps=3)
+    tv, ok = best_of(lambda: do_verify(proof), reps=3)
+    bad = dict(proof, t_x=(proof["t_x"] + 1) % r)
+    rejected = not do_verify(bad)
+    out = {"config": "cfg3 end to end: 1024 chained 32-bit bound checks, BLS12-381, prove + verify through r1cs.py over the C ABI",
+           "gates": n, "constraints": nq, "committed": m, "terms": len(terms),
+           "prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "accepted": bool(ok), "tampered_rejected": bool(rejected),
+           "of_which_transcript_of_3072_commitments_ms": t_tr * 1e3,
+           "setup_untimed_ms": {"circuit_python": t_circ * 1e3, "generators_2x65536_hashed": t_gens * 1e3, "constraint_plan": t_plan * 1e3,
+                                "commitments_V_3072": t_commit * 1e3},
+           "proof_bytes": 11 * ctx.point_bytes + 3 * 32 + len(proof["ipp"].L) + len(proof["ipp"].R) + 64}
+    plan.free()
+    ctx.close()
+    return out
+
+
 def generators():
     """get_generators("G", n) -- SURVEY 8f-1; the reference calls generator creation "very slow"
     (src/r1cs/gadgets/sparse_merkle_tree_8_ary.rs:255).  CPU figure = the C oracle on a bounded sample."""
@@ -257,6 +346,6 @@ def msm_sweep():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg5", "generators", "batch_verify", "msm_sweep"]
+    which = sys.argv[1:] or ["cfg1", "cfg3", "cfg3_e2e", "cfg5", "generators", "batch_verify", "msm_sweep"]
     for name in which:
         print(json.dumps({name: globals()[name]()}), flush=True)

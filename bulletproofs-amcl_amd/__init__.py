@@ -85,6 +85,7 @@ SYMBOLS = {
     "bp_frvec_upload": (_I, [_P, _U8P, _SZ, _PP]),
     "bp_frvec_alloc": (_I, [_P, _SZ, _PP]),
     "bp_frvec_download": (_I, [_P, _P, _SZ, _SZ, _U8P]),
+    "bp_frvec_copy": (_I, [_P, _P, _SZ, _P, _SZ, _SZ]),
     "bp_frvec_free": (_I, [_P]),
     "bp_frvec_len": (_SZ, [_P]),
     "bp_frvec_device_ptr": (_P, [_P]),
@@ -411,6 +412,13 @@ def msm_record_bytes(curve):
 
 # ---- FieldElementVector helpers -------------------------------------------------------------------------------------
 
+def _fr_copy_from(self, dst_off, src, src_off=0, n=None):
+    """self[dst_off : dst_off + n] = src[src_off : src_off + n] on the device (bp_frvec_copy); returns self"""
+    n = len(src) - src_off if n is None else n
+    _check(lib().bp_frvec_copy(self.ctx.h, self.h, dst_off, src.h, src_off, n), "bp_frvec_copy")
+    return self
+
+
 def _fr_inner_product(self, other, aoff=0, boff=0, n=None):
     """FieldElementVector::inner_product"""
     if n is None:
@@ -444,6 +452,7 @@ def _fr_vandermonde(cls, ctx, e_le32, n):
 
 
 FieldElementVector.inner_product = _fr_inner_product
+FieldElementVector.copy_from = _fr_copy_from
 FieldElementVector.hadamard_product = _fr_hadamard
 FieldElementVector.scaled_by = _fr_scaled_by
 FieldElementVector.new_vandermonde_vector = classmethod(_fr_vandermonde)

@@ -704,6 +704,15 @@ int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, u
     return BP_OK;
 }
 
+int bp_frvec_copy(bp_ctx* ctx, bp_frvec* dst, size_t dst_off, const bp_frvec* src, size_t src_off, size_t n) {
+    if (!ctx || !dst || !src) return BP_ERR_ARG;
+    if (dst_off > dst->n || n > dst->n - dst_off || src_off > src->n || n > src->n - src_off) return BP_ERR_LENGTH;
+    if (n == 0) return BP_OK;
+    int rc = set_device(ctx); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync((uint8_t*)dst->d + dst_off * 32, (const uint8_t*)src->d + src_off * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    return BP_OK;
+}
+
 int bp_frvec_free(bp_frvec* v) {
     if (!v) return BP_OK;
     if (v->owned && v->d) { (void)hipSetDevice(v->device); (void)hipFree(v->d); }

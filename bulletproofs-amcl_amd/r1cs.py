@@ -1,0 +1,180 @@
+"""Host-side mirror of the two callers of the hot path in the R1CS layer: `Prover::prove` (reference src/r1cs/prover.rs:323-560)
+and `Verifier::verify` (src/r1cs/verifier.rs:265-452), for single-phase constraint systems (no randomised second phase:
+n2 = 0 and A_I2 = A_O2 = S2 = identity).
+
+What runs where follows the reference's split: the host keeps the Merlin transcript and a handful of scalars (blinding
+polynomial, t(x), the verifier's combination weights); every vector and group operation goes through the C ABI -- commitment
+MSMs over resident [G | H | h], `flattened_constraints` (R1CSPlan), the l/r polynomials, t(x) by `special_inner_product`,
+the inner-product argument, and the verifier's MSM.  The constraint-system builder and the gadgets are NOT mirrored
+(out of scope): a circuit arrives as flat term lists.
+
+There are no reference vectors for a whole proof (the reference cannot run in this image), so what the tests establish is
+consistency -- honest proofs verify, modified ones do not -- on top of the per-kernel parity tests.
+"""
+import os
+
+import bulletproofs_amcl_amd as bp
+
+
+def _le(x):
+    return int(x).to_bytes(32, "little")
+
+
+def _int(b):
+    return int.from_bytes(b, "little")
+
+
+def padded(n):
+    return 1 << max(0, (n - 1).bit_length())
+
+
+class Generators:
+    """g, h = G1::from_msg_hash("g" / "h"), G, H = get_generators("G" / "H", n) as every gadget test of the reference builds
+    them (e.g. src/r1cs/gadgets/bound_check.rs:200-203), kept resident; GHh = [G | H | h] and GH = [G | H] are the
+    concatenations the commitments and the verifier's MSM run over (built once: the generators are protocol constants)."""
+
+    def __init__(self, ctx, n):
+        self.ctx, self.n = ctx, n
+        self.g = bp.G1Vector.from_msg_hash(ctx, [b"g"]).to_bytes()
+        self.h = bp.G1Vector.from_msg_hash(ctx, [b"h"]).to_bytes()
+        self.G = bp.get_generators(ctx, "G", n)
+        self.H = bp.get_generators(ctx, "H", n)
+        gb, hb = self.G.to_bytes(), self.H.to_bytes()
+        self.GHh = bp.G1Vector.from_bytes(ctx, gb + hb + self.h, 2 * n + 1)
+        self.gh = bp.G1Vector.from_bytes(ctx, self.g + self.h, 2)
+
+    def commit(self, v, blinding):
+        """commit_to_field_element(g, h, v, r) = v g + r h (src/r1cs/prover.rs:123)"""
+        return self.gh.multi_scalar_mul_var_time(bp.FieldElementVector.from_ints(self.ctx, [v, blinding]))
+
+
+def start_transcript(ctx, label, V):
+    t = bp.Transcript(label)
+    t.append_message(b"dom-sep", b"r1cs v1")                      # r1cs_domain_sep, src/transcript.rs:35-37
+    for Vj in V:
+        t.commit_point(ctx.curve, b"V", Vj)                       # Prover::commit, prover.rs:118-127
+    return t
+
+
+def _cat(ctx, parts):
+    """One resident scalar vector from device vectors, int lists and zero runs (an int k = k zeros): device-to-device copies
+    into a zero-initialised vector; only the short int lists are uploaded."""
+    sizes = [p if isinstance(p, int) else len(p) for p in parts]
+    out = bp.FieldElementVector.new(ctx, sum(sizes))
+    off = 0
+    for p, k in zip(parts, sizes):
+        if isinstance(p, bp.FieldElementVector):
+            out.copy_from(off, p)
+        elif not isinstance(p, int) and k:
+            out.copy_from(off, bp.FieldElementVector.from_bytes(ctx, b"".join(_le(x) for x in p), k))
+        off += k
+    return out
+
+
+def prove(ctx, gens, plan, transcript, aL, aR, aO, v_blinding, sL, sR, blindings):
+    """aL, aR, aO, sL, sR: FieldElementVectors of length n = plan.n (a power of two or not); v_blinding: FieldElementVector of
+    length m; blindings: dict with i, o, s and t1, t3, t4, t5, t6 (ints).  The transcript already holds the V commitments.
+    Returns the proof as a dict."""
+    r, cv, pb = ctx.r, ctx.curve, ctx.point_bytes
+    n, m = plan.n, plan.m
+    N = gens.n
+    pn = padded(n)
+    if N < pn:
+        raise bp.ArgError("not enough generators")                # R1CSError::InvalidGeneratorsLength, prover.rs:333,382
+    t = transcript
+    t.append_u64(b"m", m)                                         # :328
+    # A_I = <a_L, G> + <a_R, H> + i_blinding h over the resident [G | H | h]: scalars [a_L | 0.. | a_R | 0.. | i]        :346-361
+    full = lambda a, b, c: _cat(ctx, [a, N - n, b, N - n, [c]])
+    A_I1 = gens.GHh.multi_scalar_mul_var_time(full(aL, aR, blindings["i"]))
+    A_O1 = gens.GHh.multi_scalar_mul_var_time(full(aO, n, blindings["o"]))
+    S1 = gens.GHh.multi_scalar_mul_var_time(full(sL, sR, blindings["s"]))
+    for label, P in ((b"A_I1", A_I1), (b"A_O1", A_O1), (b"S1", S1)):
+        t.commit_point(cv, label, P)
+    t.append_message(b"dom-sep", b"r1cs-1phase")                  # create_randomized_constraints, :304-306
+    ident = bytes(pb)
+    for label in (b"A_I2", b"A_O2", b"S2"):
+        t.commit_point(cv, label, ident)                          # :429-431
+    y = _int(t.challenge_scalar(cv, b"y"))
+    z = _int(t.challenge_scalar(cv, b"z"))
+    wL, wR, wO, wV, _ = plan.flattened_constraints(_le(z), want_constant=False)                       # :438
+    l_poly, r_poly = bp.r1cs_prover_polys(ctx, aL, aR, aO, sL, sR, wL, wR, wO, _le(y))               # :465-486
+    tc = [_int(c) for c in bp.VecPoly3.special_inner_product(l_poly, r_poly)]                         # t1..t6, :488
+    tb = {k: blindings["t%d" % k] for k in (1, 3, 4, 5, 6)}
+    T = {k: gens.commit(tc[k - 1], tb[k]) for k in (1, 3, 4, 5, 6)}                                   # :496-500
+    for k in (1, 3, 4, 5, 6):
+        t.commit_point(cv, b"T_%d" % k, T[k])
+    u = _int(t.challenge_scalar(cv, b"u"))
+    x = _int(t.challenge_scalar(cv, b"x"))
+    tb[2] = _int(wV.inner_product(v_blinding)) if m else 0                                             # :513
+    t_x = sum(tc[k - 1] * pow(x, k, r) for k in range(1, 7)) % r
+    t_x_blinding = sum(tb[k] * pow(x, k, r) for k in range(1, 7)) % r
+    l_vec, r_vec, Gf, Hf = bp.r1cs_ipp_inputs(ctx, l_poly.eval(_le(x)), r_poly.eval(_le(x)), _le(y), _le(u), n, pn)   # :526-563
+    e_blinding = x * (blindings["i"] + x * (blindings["o"] + x * blindings["s"])) % r                  # :539-543, second-phase terms = 0
+    for label, s in ((b"t_x", t_x), (b"t_x_blinding", t_x_blinding), (b"e_blinding", e_blinding)):
+        t.commit_scalar(cv, label, _le(s))
+    w = _int(t.challenge_scalar(cv, b"w"))
+    Q = gens.gh.multi_scalar_mul_var_time(bp.FieldElementVector.from_ints(ctx, [w, 0]))              # Q = w g, :552
+    Gp = gens.G if pn == N else bp.G1Vector.from_bytes(ctx, gens.G.to_bytes(0, pn), pn)
+    Hp = gens.H if pn == N else bp.G1Vector.from_bytes(ctx, gens.H.to_bytes(0, pn), pn)
+    ipp = bp.IPP.create_ipp(ctx, t, Q, Gf, Hf, Gp, Hp, l_vec, r_vec)                                   # :567-576
+    return {"A_I1": A_I1, "A_O1": A_O1, "S1": S1, "T": T, "t_x": t_x, "t_x_blinding": t_x_blinding, "e_blinding": e_blinding, "ipp": ipp}
+
+
+def verify(ctx, gens, plan, transcript, V, proof, r_weight=None):
+    """True iff the verification equation holds (the reference evaluates ONE MSM, verifier.rs:431-451; here the [G | H] part
+    runs over the resident generators and the few thousand remaining terms over an uploaded vector, and the two partial
+    sums are added -- the same group element)."""
+    r, cv, pb = ctx.r, ctx.curve, ctx.point_bytes
+    n, m = plan.n, plan.m
+    N = gens.n
+    pn = padded(n)
+    if N < pn or len(V) != m:
+        return False
+    t = transcript
+    ident = bytes(pb)
+    t.append_u64(b"m", m)                                         # verifier.rs:278
+    for label in (b"A_I1", b"A_O1", b"S1"):
+        t.commit_point(cv, label, proof[label.decode()])
+    t.append_message(b"dom-sep", b"r1cs-1phase")
+    for label in (b"A_I2", b"A_O2", b"S2"):
+        t.commit_point(cv, label, ident)
+    y = _int(t.challenge_scalar(cv, b"y"))
+    z = _int(t.challenge_scalar(cv, b"z"))
+    for k in (1, 3, 4, 5, 6):
+        t.commit_point(cv, b"T_%d" % k, proof["T"][k])
+    u = _int(t.challenge_scalar(cv, b"u"))
+    x = _int(t.challenge_scalar(cv, b"x"))
+    for label in (b"t_x", b"t_x_blinding", b"e_blinding"):
+        t.commit_scalar(cv, label, _le(proof[label.decode()]))
+    w = _int(t.challenge_scalar(cv, b"w"))
+    wL, wR, wO, wV, wc = plan.flattened_constraints(_le(z))      # :329
+    wc = _int(wc)
+    ipp = proof["ipp"]
+    a, b = _int(ipp.a), _int(ipp.b)
+    y_inv = pow(y, -1, r)
+    y_inv_vec = bp.FieldElementVector.new_vandermonde_vector(ctx, _le(y_inv), n)
+    delta = _int(wR.hadamard_product(y_inv_vec).inner_product(wL))                                      # :344-352
+    try:
+        u_sq, u_inv_sq, g_sc, h_sc = bp.r1cs_verifier_scalars(ctx, t, ipp.L, ipp.R, pn, n, wL, wR, wO, _le(y_inv), _le(x), _le(u), ipp.a, ipp.b)
+    except bp.VerificationError:
+        return False
+    rr = r_weight if r_weight is not None else int.from_bytes(os.urandom(32), "little") % r             # :392
+    x2, x3 = x * x % r, pow(x, 3, r)
+    tx, txb, eb = proof["t_x"], proof["t_x_blinding"], proof["e_blinding"]
+    head = [x, x2, x3, u * x % r, u * x2 % r, u * x3 % r]                                               # A_I1, A_O1, S1, A_I2, A_O2, S2
+    Ts = [rr * x % r, rr * x3 % r, rr * pow(x, 4, r) % r, rr * pow(x, 5, r) % r, rr * pow(x, 6, r) % r]  # :398-408
+    w_g = (w * (tx - a * b) + rr * (x2 * (wc + delta) - tx)) % r                                        # :422
+    p_h = (-(eb + rr * txb)) % r                                                                        # :425
+    parts = [head] + ([wV.scaled_by(_le(rr * x2 % r))] if m else []) + [Ts, [w_g, p_h]]                 # :416
+    small_sc = _cat(ctx, parts).to_bytes() + u_sq + u_inv_sq          # 6 + m + 7 + 2 lg n scalars
+    small_pts = proof["A_I1"] + proof["A_O1"] + proof["S1"] + ident * 3 + b"".join(V) + b"".join(proof["T"][k] for k in (1, 3, 4, 5, 6))
+    small_pts += gens.g + gens.h + ipp.L + ipp.R
+    k = len(small_sc) // 32
+    if k * pb != len(small_pts):
+        return False
+    part1 = bp.G1Vector.from_bytes(ctx, small_pts, k).multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, small_sc, k))
+    # [G | H | h] resident: g_scalars | 0.. | h_scalars | 0.. | 0
+    big_sc = _cat(ctx, [g_sc, N - pn, h_sc, N - pn, 1])
+    part2 = gens.GHh.multi_scalar_mul_var_time(big_sc)
+    both = bp.G1Vector.from_bytes(ctx, part1 + part2, 2).multi_scalar_mul_var_time(bp.FieldElementVector.from_ints(ctx, [1, 1]))
+    return both == ident

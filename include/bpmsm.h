@@ -113,6 +113,9 @@ int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1
 int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec** out);
 int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out); /* zeros */
 int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, uint8_t* out_le32);
+/* dst[dst_off .. dst_off + n) = src[src_off .. src_off + n), device to device on the context's stream (concatenations such as
+ * [a_L | a_R | blinding] for commit_to_field_element_vectors, src/r1cs/prover.rs:346-361, without a trip through the host). */
+int bp_frvec_copy(bp_ctx* ctx, bp_frvec* dst, size_t dst_off, const bp_frvec* src, size_t src_off, size_t n);
 int bp_frvec_free(bp_frvec* v);
 size_t bp_frvec_len(const bp_frvec* v);
 void* bp_frvec_device_ptr(bp_frvec* v);
