@@ -221,8 +221,9 @@ def cfg3_e2e():
     vb = [int.from_bytes(random_scalars(r, info.fr_bits, 1, 9000 + j), "little") for j in range(m)]
     dVB = small(vb)
     t0 = time.perf_counter()
-    V = [gens.commit(v[j], vb[j]) for j in range(m)]
+    V = gens.commit_many(v, vb)
     t_commit = time.perf_counter() - t0
+    assert V[5] == gens.commit(v[5], vb[5]) and V[-1] == gens.commit(v[-1], vb[-1])
     sL = bp.FieldElementVector.from_bytes(ctx, random_scalars(r, info.fr_bits, n, 9100), n)
     sR = bp.FieldElementVector.from_bytes(ctx, random_scalars(r, info.fr_bits, n, 9101), n)
     bl = {k: int.from_bytes(random_scalars(r, info.fr_bits, 1, 9200 + i), "little") for i, k in enumerate(("i", "o", "s", "t1", "t3", "t4", "t5", "t6"))}

@@ -80,6 +80,7 @@ SYMBOLS = {
     "bp_g1vec_wrap_device": (_I, [_P, _P, _SZ, _PP]),
     "bp_g1vec_fixed_base_mul": (_I, [_P, _P, _PP]),
     "bp_g1vec_scalar_mul": (_I, [_P, _P, _P, _PP]),
+    "bp_g1vec_commit_pairs": (_I, [_P, _U8P, _U8P, _P, _P, _PP]),
     "bp_g1vec_from_msg_hash": (_I, [_P, _U8P, _P, _SZ, _PP]),
     "bp_get_generators": (_I, [_P, _U8P, _SZ, ctypes.c_uint64, _SZ, _PP]),
     "bp_frvec_upload": (_I, [_P, _U8P, _SZ, _PP]),
@@ -268,6 +269,13 @@ class G1Vector:
         h = ctypes.c_void_p()
         _check(lib().bp_g1vec_from_msg_hash(ctx.h, b"".join(messages), ctypes.cast(offs, ctypes.c_void_p), len(messages), ctypes.byref(h)),
                "bp_g1vec_from_msg_hash")
+        return cls(ctx, h)
+
+    @classmethod
+    def commit_pairs(cls, ctx, g_le, h_le, k1, k2):
+        """[k1_i * g + k2_i * h]: batched commit_to_field_element / binary_scalar_mul with fixed g, h (src/r1cs/prover.rs:123)"""
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_commit_pairs(ctx.h, bytes(g_le), bytes(h_le), k1.h, k2.h, ctypes.byref(h)), "bp_g1vec_commit_pairs")
         return cls(ctx, h)
 
     def scaled_by(self, scalars):

@@ -452,6 +452,27 @@ static int flattened_constraints_impl(bp_ctx* ctx, const bp_r1cs_plan* p, const 
     return rc;
 }
 
+template <class C>
+static int commit_pairs_impl(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const bp_frvec* k1, const bp_frvec* k2, bp_g1vec* out) {
+    // the two fixed points go through the same upload path as any other points (canonical bytes -> resident Montgomery rows)
+    bp_g1vec* gh = nullptr;
+    std::vector<uint8_t> both(4 * (size_t)(4 * C::Fp::NW));
+    memcpy(both.data(), g_le, 2 * (size_t)(4 * C::Fp::NW));
+    memcpy(both.data() + 2 * (size_t)(4 * C::Fp::NW), h_le, 2 * (size_t)(4 * C::Fp::NW));
+    int rc = bp_g1vec_upload(ctx, both.data(), 2, BP_FMT_LE, &gh);
+    if (rc) return rc;
+    AffPacked<C> hostgh[2];
+    if (hipMemcpyAsync(hostgh, gh->d, sizeof hostgh, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        bp_g1vec_free(gh);
+        return BP_ERR_DEVICE;
+    }
+    bp_g1vec_free(gh);
+    hipLaunchKernelGGL(k_commit_pairs<C>, dim3(blocks_for(k1->n)), dim3(kBlock), 0, ctx->stream, hostgh[0], hostgh[1], (const ScalarWords*)k1->d,
+                       (const ScalarWords*)k2->d, k1->n, (AffPacked<C>*)out->d);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
 extern "C" {
 
 // ---- transcript ---------------------------------------------------------------------------------------------
@@ -823,6 +844,18 @@ int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_fa
     if (m == 0) return BP_OK;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     IPP_DISPATCH(ctx->curve, I::verify_batch(ctx, n, lg_n, G_factors, H_factors, G, H, proofs, m, weights_le32));
+}
+
+int bp_g1vec_commit_pairs(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const bp_frvec* k1, const bp_frvec* k2, bp_g1vec** out) {
+    if (!ctx || !g_le || !h_le || !k1 || !k2 || !out) return BP_ERR_ARG;
+    *out = nullptr;
+    if (k1->n != k2->n) return BP_ERR_LENGTH;
+    int rc = bp_g1vec_alloc(ctx, k1->n, out);
+    if (rc || k1->n == 0) return rc;
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = commit_pairs_impl<Bls381>(ctx, g_le, h_le, k1, k2, *out);
+    else rc = commit_pairs_impl<Bn254>(ctx, g_le, h_le, k1, k2, *out);
+    if (rc) { bp_g1vec_free(*out); *out = nullptr; }
+    return rc;
 }
 
 int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,

@@ -379,6 +379,17 @@ BP_HD Xyzz<C> xyzz_mul2_words(const ScalarWords& k1, const Aff<C>& p, const Scal
     return acc;
 }
 
+// Batched `commit_to_field_element(g, h, m, r)` = `g.binary_scalar_mul(h, m, r)` = m g + r h with FIXED g, h and one (m, r)
+// pair per lane (/root/reference src/r1cs/prover.rs:123: one per committed value -- 3 072 in BASELINE config 3 -- and
+// :496-500 for T_1..T_6).  out[i] = k1[i] * g + k2[i] * h.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_commit_pairs(AffPacked<C> g, AffPacked<C> h, const ScalarWords* __restrict__ k1,
+                                                         const ScalarWords* __restrict__ k2, size_t n, AffPacked<C>* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = aff_pack(xyzz_to_aff<C>(xyzz_mul2_words<C>(k1[i], aff_unpack(g), k2[i], aff_unpack(h))));
+}
+
 // One lane per (vector, i):  lanes [0, h) fold G, lanes [h, 2h) fold H; every lane i < h also folds a and b.
 //   a_L[i] = a_L[i] u + u^-1 a_R[i] ;  b_L[i] = b_L[i] u^-1 + u b_R[i]                         (src/ipp.rs:116-117,182-183)
 //   G_L[i] = (u^-1 Gf_L[i]) G_L[i] + (u Gf_R[i]) G_R[i] ;  H_L[i] = (u Hf_L[i]) H_L[i] + (u^-1 Hf_R[i]) H_R[i]   (:119-129,185-187)

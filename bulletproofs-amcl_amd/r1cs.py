@@ -47,6 +47,16 @@ class Generators:
         """commit_to_field_element(g, h, v, r) = v g + r h (src/r1cs/prover.rs:123)"""
         return self.gh.multi_scalar_mul_var_time(bp.FieldElementVector.from_ints(self.ctx, [v, blinding]))
 
+    def commit_many(self, values, blindings):
+        """[v_j g + r_j h] for all committed values at once (one lane each, bp_g1vec_commit_pairs) -> list of point bytes"""
+        ctx, pb = self.ctx, self.ctx.point_bytes
+        if not values:
+            return []
+        k1 = bp.FieldElementVector.from_ints(ctx, values)
+        k2 = bp.FieldElementVector.from_ints(ctx, blindings)
+        out = bp.G1Vector.commit_pairs(ctx, self.g, self.h, k1, k2).to_bytes()
+        return [out[j * pb:(j + 1) * pb] for j in range(len(values))]
+
 
 def start_transcript(ctx, label, V):
     t = bp.Transcript(label)

@@ -96,6 +96,9 @@ int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out
 /* out[i] = k[i] * G.  Batched form of `&G1::generator() * &FieldElement` (src/utils/mod.rs:34); used to build
  * synthetic generator vectors on the device. */
 int bp_g1vec_fixed_base_mul(bp_ctx* ctx, const bp_frvec* k, bp_g1vec** out);
+/* Batched `commit_to_field_element(g, h, m, r)` = `g.binary_scalar_mul(h, m, r)` (src/r1cs/prover.rs:123,496-500):
+ * out[i] = k1[i] * g + k2[i] * h for fixed points g, h (x || y little-endian) and one scalar pair per commitment. */
+int bp_g1vec_commit_pairs(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const bp_frvec* k1, const bp_frvec* k2, bp_g1vec** out);
 /* Hash to G1, batched: out[i] = `G1::from_msg_hash(message i)` (amcl_wrapper; the reference calls it at
  * src/utils/mod.rs:20 and for the `g`, `h` of every gadget test, e.g. src/r1cs/gadgets/bound_check.rs:202-203).
  * Message i = msgs[offsets[i] .. offsets[i+1]); offsets has n + 1 entries, offsets[0] == 0.

@@ -393,3 +393,27 @@ def test_r1cs_plan_argument_checks(bp, ctxs):
     other.close()
     wL, wR, wO, wV, wc = plan.flattened_constraints((5).to_bytes(32, "little"))
     assert int.from_bytes(wc, "little") == (ctx.r - 15) and ints(wL.to_bytes()) == [0] * 4
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_commit_pairs_vs_oracle(bp, ctxs, name):
+    """bp_g1vec_commit_pairs = batched `commit_to_field_element(g, h, m, r)` / `g.binary_scalar_mul(h, m, r)`
+    (src/r1cs/prover.rs:123,496-500) against the oracle's binary_scalar_mul, including the degenerate point pairs."""
+    ctx = ctxs[name]
+    cid, r, pb = ctx.curve, ctx.r, ctx.point_bytes
+    gen = O.generator(cid)
+    g = O.g1_mul(cid, (7).to_bytes(32, "little"), gen)
+    h = O.g1_mul(cid, (11).to_bytes(32, "little"), gen)
+    neg_g = O.g1_mul(cid, (r - 7).to_bytes(32, "little"), gen)
+    specials = [0, 1, 2, r - 1, r - 2, (1 << 128) - 1, 1 << 200]
+    k1 = specials + ints(O.random_scalars(cid, 7700, 60))
+    k2 = list(reversed(specials)) + ints(O.random_scalars(cid, 7701, 60))
+    dev = lambda xs: bp.FieldElementVector.from_ints(ctx, xs)
+    for P, Q in ((g, h), (g, g), (g, neg_g), (bytes(pb), h), (g, bytes(pb))):
+        got = bp.G1Vector.commit_pairs(ctx, P, Q, dev(k1), dev(k2)).to_bytes()
+        for j, (a, b) in enumerate(zip(k1, k2)):
+            want = O.binary_scalar_mul(cid, P, Q, a.to_bytes(32, "little"), b.to_bytes(32, "little"))
+            assert got[j * pb:(j + 1) * pb] == want, (j, a, b)
+    assert len(bp.G1Vector.commit_pairs(ctx, g, h, dev([]), dev([]))) == 0
+    with pytest.raises(bp.ValueError_):
+        bp.G1Vector.commit_pairs(ctx, g, h, dev([1, 2]), dev([1]))

@@ -53,7 +53,8 @@ def random_satisfiable_system(rng, r, n, m, nq):
 
 def run_prove(bp, R1, ctx, gens, cons, n, m, aL, aR, aO, v, v_blinding, rng):
     r = ctx.r
-    V = [gens.commit(v[j], v_blinding[j]) for j in range(m)]
+    V = gens.commit_many(v, v_blinding)                       # batched commit_to_field_element ...
+    assert V == [gens.commit(v[j], v_blinding[j]) for j in range(m)]      # ... equals the 2-term MSMs
     terms = [(q, k, i, c) for q, ts in enumerate(cons) for k, i, c in ts]
     plan = bp.R1CSPlan(ctx, terms, len(cons), n, m)
     dev = lambda xs: bp.FieldElementVector.from_ints(ctx, xs)
