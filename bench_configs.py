@@ -228,11 +228,22 @@ def cfg3_e2e():
     sR = bp.FieldElementVector.from_bytes(ctx, random_scalars(r, info.fr_bits, n, 9101), n)
     bl = {k: int.from_bytes(random_scalars(r, info.fr_bits, 1, 9200 + i), "little") for i, k in enumerate(("i", "o", "s", "t1", "t3", "t4", "t5", "t6"))}
 
-    def do_prove():
-        return R1.prove(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), dAL, dAR, dAO, dVB, sL, sR, bl)
+    order = ("i", "o", "s", "t1", "t3", "t4", "t5", "t6")
+    bl_bytes = b"".join(bl[k].to_bytes(32, "little") for k in order)
+    Vb = b"".join(V)
+
+    def do_prove():       # one library call: the orchestration is C++ inside libbpmsm.so (bp_capi_r1cs.hip)
+        return bp.r1cs_prove(ctx, R1.start_transcript(ctx, b"cfg3", V), plan, gens.G, gens.H, gens.g, gens.h, dAL, dAR, dAO, dVB, sL, sR, bl_bytes)
 
     def do_verify(proof):
-        return R1.verify(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), V, proof)
+        try:
+            bp.r1cs_verify(ctx, R1.start_transcript(ctx, b"cfg3", V), plan, gens.G, gens.H, gens.g, gens.h, Vb, n, proof, os.urandom(31) + b"\0")
+            return True
+        except bp.VerificationError:
+            return False
+
+    def py_prove():       # the same orchestration in the Python mirror (r1cs.py)
+        return R1.prove(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), dAL, dAR, dAO, dVB, sL, sR, bl)
 
     t0 = time.perf_counter()
     R1.start_transcript(ctx, b"cfg3", V)
@@ -240,15 +251,24 @@ def cfg3_e2e():
     proof = do_prove()
     tp, proof = best_of(do_prove, reps=3)
     tv, ok = best_of(lambda: do_verify(proof), reps=3)
-    bad = dict(proof, t_x=(proof["t_x"] + 1) % r)
-    rejected = not do_verify(bad)
-    out = {"config": "cfg3 end to end: 1024 chained 32-bit bound checks, BLS12-381, prove + verify through r1cs.py over the C ABI",
+    tpp, pyproof = best_of(py_prove, reps=2)
+    tpv, pyok = best_of(lambda: R1.verify(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), V, pyproof), reps=2)
+    ipp = pyproof["ipp"]
+    same = proof == (pyproof["A_I1"] + pyproof["A_O1"] + pyproof["S1"] + bytes(3 * ctx.point_bytes) + b"".join(pyproof["T"][k] for k in (1, 3, 4, 5, 6))
+                     + b"".join(int(pyproof[k]).to_bytes(32, "little") for k in ("t_x", "t_x_blinding", "e_blinding")) + ipp.L + ipp.R + ipp.a + ipp.b)
+    bad = bytearray(proof)
+    bad[11 * ctx.point_bytes] ^= 1                                  # t_x
+    rejected = not do_verify(bytes(bad))
+    out = {"config": "cfg3 end to end: 1024 chained 32-bit bound checks, BLS12-381, bp_r1cs_prove + bp_r1cs_verify (host orchestration in C++ "
+                     "inside libbpmsm.so over its own C ABI)",
            "gates": n, "constraints": nq, "committed": m, "terms": len(terms),
            "prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "accepted": bool(ok), "tampered_rejected": bool(rejected),
+           "python_mirror_prove_ms": tpp * 1e3, "python_mirror_verify_ms": tpv * 1e3, "python_mirror_accepts": bool(pyok),
+           "library_and_python_proofs_identical": bool(same),
            "of_which_transcript_of_3072_commitments_ms": t_tr * 1e3,
            "setup_untimed_ms": {"circuit_python": t_circ * 1e3, "generators_2x65536_hashed": t_gens * 1e3, "constraint_plan": t_plan * 1e3,
                                 "commitments_V_3072": t_commit * 1e3},
-           "proof_bytes": 11 * ctx.point_bytes + 3 * 32 + len(proof["ipp"].L) + len(proof["ipp"].R) + 64}
+           "proof_bytes": len(proof)}
     plan.free()
     ctx.close()
     return out

@@ -112,6 +112,9 @@ SYMBOLS = {
     "bp_r1cs_plan_create": (_I, [_P, _SZ, _P, _U8P, _P, _U8P, _SZ, _SZ, _SZ, _PP]),
     "bp_r1cs_plan_free": (_I, [_P]),
     "bp_r1cs_flattened_constraints": (_I, [_P, _P, _U8P, _PP, _U8P]),
+    "bp_r1cs_proof_bytes": (_SZ, [_I, _SZ]),
+    "bp_r1cs_prove": (_I, [_P, _P, _P, _P, _P, _U8P, _U8P, _P, _P, _P, _P, _P, _P, _U8P, _U8P, _SZ]),
+    "bp_r1cs_verify": (_I, [_P, _P, _P, _P, _P, _U8P, _U8P, _U8P, _SZ, _SZ, _U8P, _SZ, _U8P]),
     "bp_r1cs_prover_polys": (_I, [_P, _PP, _U8P, _PP]),
     "bp_r1cs_ipp_inputs": (_I, [_P, _P, _P, _U8P, _U8P, _SZ, _SZ, _PP]),
     "bp_r1cs_verifier_scalars": (_I, [_P, _P, _U8P, _U8P, _SZ, _SZ, _SZ, _P, _P, _P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _PP, _PP]),
@@ -712,6 +715,25 @@ class R1CSPlan:
             self.free()
         except Exception:
             pass
+
+
+def r1cs_prove(ctx, transcript, plan, G, H, g_le, h_le, a_L, a_R, a_O, v_blinding, s_L, s_R, blindings_le32):
+    """Prover::prove (src/r1cs/prover.rs:323-560) as one library call (bp_r1cs_prove) -> proof bytes.
+    blindings_le32: i, o, s, t1, t3, t4, t5, t6 (8 x 32 bytes)."""
+    n = len(a_L)
+    size = lib().bp_r1cs_proof_bytes(ctx.curve, n)
+    out = ctypes.create_string_buffer(size)
+    _check(lib().bp_r1cs_prove(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), a_L.h, a_R.h, a_O.h,
+                               v_blinding.h if v_blinding is not None and len(v_blinding) else None, s_L.h, s_R.h, bytes(blindings_le32), out, size),
+           "bp_r1cs_prove")
+    return out.raw
+
+
+def r1cs_verify(ctx, transcript, plan, G, H, g_le, h_le, V_le, n, proof, r_le32):
+    """Verifier::verify (src/r1cs/verifier.rs:265-452) as one library call; raises VerificationError."""
+    m = len(V_le) // ctx.point_bytes
+    _check(lib().bp_r1cs_verify(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), bytes(V_le) or None, n, m, bytes(proof), len(proof),
+                                bytes(r_le32)), "bp_r1cs_verify")
 
 
 def r1cs_prover_polys(ctx, a_L, a_R, a_O, s_L, s_R, wL, wR, wO, y_le32):

@@ -1,0 +1,365 @@
+// bp_capi_r1cs.hip -- host orchestration of the two callers of the hot path in the R1CS layer, written against the PUBLIC C ABI
+// of this library (include/bpmsm.h) plus host field arithmetic: `Prover::prove` (/root/reference src/r1cs/prover.rs:323-560)
+// and `Verifier::verify` (src/r1cs/verifier.rs:265-452) for single-phase constraint systems (n2 = 0: A_I2 = A_O2 = S2 = O).
+// The host keeps the transcript and a handful of scalars, exactly the reference's split; everything with a vector or a group
+// element in it is a bp_* call.  bulletproofs-amcl_amd/r1cs.py is the same orchestration in the Python mirror; the tests
+// require both to produce the same proof bytes.
+#include <vector>
+
+#include "bp_internal.hpp"
+
+using namespace bp;
+
+namespace {
+
+template <class F> Fe<F> fr_in(const uint8_t* le32) {
+    uint32_t w[8];
+    memcpy(w, le32, 32);
+    return fe_to_mont<F>(fe_unpack_words<F>(w));
+}
+template <class F> void fr_out(const Fe<F>& x_mont, uint8_t* le32) {
+    uint32_t w[8];
+    fe_pack_words<F>(w, fe_from_mont<F>(x_mont));
+    memcpy(le32, w, 32);
+}
+
+// owns every temporary handle of one call
+struct Temps {
+    std::vector<bp_frvec*> fr;
+    std::vector<bp_g1vec*> g1;
+    bp_frvec* keep(bp_frvec* v) { fr.push_back(v); return v; }
+    bp_g1vec* keep(bp_g1vec* v) { g1.push_back(v); return v; }
+    ~Temps() {
+        for (auto* v : fr) bp_frvec_free(v);
+        for (auto* v : g1) bp_g1vec_free(v);
+    }
+};
+
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+inline size_t padded_len(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+inline size_t lg_of(size_t p) { size_t l = 0; while (((size_t)1 << l) < p) l++; return l; }
+
+// scalars held on the host -> one resident vector
+int upload_scalars(bp_ctx* ctx, Temps& T, const std::vector<uint8_t>& le, bp_frvec** out) {
+    RC(bp_frvec_upload(ctx, le.data(), le.size() / 32, out));
+    T.keep(*out);
+    return BP_OK;
+}
+
+// sum_i scalars[i] * points[i] for a few host-side points and scalars (T_k, Q, ...)
+int small_msm(bp_ctx* ctx, Temps& T, const std::vector<uint8_t>& pts_le, const std::vector<uint8_t>& sc_le, size_t pb, uint8_t* out_le) {
+    bp_g1vec* p = nullptr;
+    bp_frvec* s = nullptr;
+    RC(bp_g1vec_upload(ctx, pts_le.data(), pts_le.size() / pb, BP_FMT_LE, &p));
+    T.keep(p);
+    RC(upload_scalars(ctx, T, sc_le, &s));
+    return bp_msm_g1(ctx, p, s, out_le);
+}
+
+template <class C>
+struct R1cs {
+    using F = typename C::Fr;
+    static constexpr size_t pb = 2 * 4 * C::Fp::NW;
+    static constexpr size_t row = sizeof(AffPacked<C>);
+
+    // [G[0..n) | H[0..n) | h] as one resident vector (device-to-device; the generators stay where they are)
+    static int cat_GHh(bp_ctx* ctx, Temps& T, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t n, bp_g1vec** out) {
+        bp_g1vec *v = nullptr, *hv = nullptr;
+        RC(bp_g1vec_alloc(ctx, 2 * n + 1, &v));
+        T.keep(v);
+        RC(bp_g1vec_upload(ctx, h_le, 1, BP_FMT_LE, &hv));
+        T.keep(hv);
+        hipStream_t s = ctx->stream;
+        HIPCHK(hipMemcpyAsync(v->d, G->d, n * row, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((uint8_t*)v->d + n * row, H->d, n * row, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((uint8_t*)v->d + 2 * n * row, hv->d, row, hipMemcpyDeviceToDevice, s));
+        *out = v;
+        return BP_OK;
+    }
+
+    // <a, G> + <b, H> + c h     (commit_to_field_element_vectors, prover.rs:346-361); b == nullptr: <a, G> + c h
+    static int commit_vectors(bp_ctx* ctx, Temps& T, const bp_g1vec* GHh, size_t n, const bp_frvec* a, const bp_frvec* b, const Fe<F>& c, uint8_t* out_le) {
+        bp_frvec *sc = nullptr, *one = nullptr;
+        RC(bp_frvec_alloc(ctx, 2 * n + 1, &sc));
+        T.keep(sc);
+        RC(bp_frvec_copy(ctx, sc, 0, a, 0, n));
+        if (b) RC(bp_frvec_copy(ctx, sc, n, b, 0, n));
+        std::vector<uint8_t> cle(32);
+        fr_out<F>(c, cle.data());
+        RC(upload_scalars(ctx, T, cle, &one));
+        RC(bp_frvec_copy(ctx, sc, 2 * n, one, 0, 1));
+        return bp_msm_g1(ctx, GHh, sc, out_le);
+    }
+
+    static Fe<F> challenge(bp_transcript* t, int curve, const char* label) {
+        uint8_t b[32];
+        bp_transcript_challenge_scalar(t, curve, label, b);
+        return fr_in<F>(b);
+    }
+
+    // proof layout: A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6 | t_x t_x_blinding e_blinding | L[lg] R[lg] | a b
+    static size_t proof_bytes(size_t n) { return 11 * pb + 96 + 2 * lg_of(padded_len(n)) * pb + 64; }
+
+    static int prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                     const uint8_t* h_le, const bp_frvec* aL, const bp_frvec* aR, const bp_frvec* aO, const bp_frvec* v_blinding, const bp_frvec* sL,
+                     const bp_frvec* sR, const uint8_t* bl, uint8_t* proof) {
+        Temps T;
+        const int cv = ctx->curve;
+        const size_t n = aL->n, m = v_blinding ? v_blinding->n : 0, pn = padded_len(n), lg = lg_of(pn);
+        uint8_t* P = proof;                                       // the 11 points
+        uint8_t* S = proof + 11 * pb;                             // the 3 scalars
+        uint8_t* Lp = S + 96;
+        uint8_t* Rp = Lp + lg * pb;
+        uint8_t* ab = Rp + lg * pb;
+        memset(proof, 0, proof_bytes(n));
+        const Fe<F> i_bl = fr_in<F>(bl), o_bl = fr_in<F>(bl + 32), s_bl = fr_in<F>(bl + 64);
+        Fe<F> tb[7];
+        tb[1] = fr_in<F>(bl + 96); tb[3] = fr_in<F>(bl + 128); tb[4] = fr_in<F>(bl + 160); tb[5] = fr_in<F>(bl + 192); tb[6] = fr_in<F>(bl + 224);
+        RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // prover.rs:328
+        bp_g1vec* GHh = nullptr;
+        RC(cat_GHh(ctx, T, G, H, h_le, n, &GHh));
+        RC(commit_vectors(ctx, T, GHh, n, aL, aR, i_bl, P + 0 * pb));                                          // A_I1  :346-354
+        RC(commit_vectors(ctx, T, GHh, n, aO, nullptr, o_bl, P + 1 * pb));                                     // A_O1  :357
+        RC(commit_vectors(ctx, T, GHh, n, sL, sR, s_bl, P + 2 * pb));                                          // S1    :360-361
+        RC(bp_transcript_commit_point(t, cv, "A_I1", P + 0 * pb));
+        RC(bp_transcript_commit_point(t, cv, "A_O1", P + 1 * pb));
+        RC(bp_transcript_commit_point(t, cv, "S1", P + 2 * pb));
+        RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));  // :304-306
+        RC(bp_transcript_commit_point(t, cv, "A_I2", P + 3 * pb));                                             // identity, :429-431
+        RC(bp_transcript_commit_point(t, cv, "A_O2", P + 4 * pb));
+        RC(bp_transcript_commit_point(t, cv, "S2", P + 5 * pb));
+        const Fe<F> y = challenge(t, cv, "y"), z = challenge(t, cv, "z");
+        uint8_t yle[32], zle[32];
+        fr_out<F>(y, yle); fr_out<F>(z, zle);
+        bp_frvec* w[4] = {};
+        RC(bp_r1cs_flattened_constraints(ctx, plan, zle, w, nullptr));                                         // :438
+        for (auto* v : w) T.keep(v);
+        const bp_frvec* in8[8] = {aL, aR, aO, sL, sR, w[0], w[1], w[2]};
+        bp_frvec* lr[6] = {};
+        RC(bp_r1cs_prover_polys(ctx, in8, yle, lr));                                                           // :465-486
+        for (auto* v : lr) T.keep(v);
+        bp_frvec* zero = nullptr;
+        RC(bp_frvec_alloc(ctx, n, &zero));
+        T.keep(zero);
+        const bp_frvec* lpoly[4] = {zero, lr[0], lr[1], lr[2]};
+        const bp_frvec* rpoly[4] = {lr[3], lr[4], zero, lr[5]};
+        uint8_t tcoef[6 * 32];
+        RC(bp_vecpoly3_special_inner_product(ctx, lpoly, rpoly, tcoef));                                       // t1..t6, :488
+        Fe<F> tc[7];
+        for (int k = 1; k <= 6; k++) tc[k] = fr_in<F>(tcoef + 32 * (k - 1));
+        std::vector<uint8_t> gh(2 * pb);
+        memcpy(gh.data(), g_le, pb);
+        memcpy(gh.data() + pb, h_le, pb);
+        const int tk[5] = {1, 3, 4, 5, 6};
+        static const char* const tlabel[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
+        for (int j = 0; j < 5; j++) {                                                                          // :496-500
+            std::vector<uint8_t> sc(64);
+            fr_out<F>(tc[tk[j]], sc.data());
+            fr_out<F>(tb[tk[j]], sc.data() + 32);
+            RC(small_msm(ctx, T, gh, sc, pb, P + (6 + j) * pb));
+        }
+        for (int j = 0; j < 5; j++) RC(bp_transcript_commit_point(t, cv, tlabel[j], P + (6 + j) * pb));
+        const Fe<F> u = challenge(t, cv, "u"), x = challenge(t, cv, "x");
+        uint8_t ule[32], xle[32];
+        fr_out<F>(u, ule); fr_out<F>(x, xle);
+        tb[2] = fe_zero<F>();
+        if (m) {                                                                                               // :513
+            uint8_t ip[32];
+            RC(bp_fr_inner_product(ctx, w[3], 0, v_blinding, 0, m, ip));
+            tb[2] = fr_in<F>(ip);
+        }
+        Fe<F> t_x = fe_zero<F>(), t_xb = fe_zero<F>(), xp = fe_one<F>();
+        for (int k = 1; k <= 6; k++) {
+            xp = fe_mul(xp, x);
+            t_x = fe_add(t_x, fe_mul(tc[k], xp));
+            t_xb = fe_add(t_xb, fe_mul(tb[k], xp));
+        }
+        bp_frvec *l_eval = nullptr, *r_eval = nullptr;
+        RC(bp_vecpoly_eval(ctx, lpoly, 3, xle, &l_eval));                                                      // :522-523
+        T.keep(l_eval);
+        RC(bp_vecpoly_eval(ctx, rpoly, 3, xle, &r_eval));
+        T.keep(r_eval);
+        bp_frvec* ippin[4] = {};
+        RC(bp_r1cs_ipp_inputs(ctx, l_eval, r_eval, yle, ule, n, pn, ippin));                                   // :526-563
+        for (auto* v : ippin) T.keep(v);
+        const Fe<F> e_bl = fe_mul(x, fe_add(i_bl, fe_mul(x, fe_add(o_bl, fe_mul(x, s_bl)))));                  // :539-543 (second phase = 0)
+        fr_out<F>(t_x, S); fr_out<F>(t_xb, S + 32); fr_out<F>(e_bl, S + 64);
+        RC(bp_transcript_commit_scalar(t, cv, "t_x", S));
+        RC(bp_transcript_commit_scalar(t, cv, "t_x_blinding", S + 32));
+        RC(bp_transcript_commit_scalar(t, cv, "e_blinding", S + 64));
+        const Fe<F> wch = challenge(t, cv, "w");
+        uint8_t Q[pb];
+        {
+            std::vector<uint8_t> sc(64, 0);
+            fr_out<F>(wch, sc.data());
+            RC(small_msm(ctx, T, gh, sc, pb, Q));                                                              // Q = w g, :552
+        }
+        bp_g1vec *Gp = nullptr, *Hp = nullptr;                                                                 // G[0..pn), H[0..pn): views
+        RC(bp_g1vec_wrap_device(ctx, G->d, pn, &Gp));
+        T.keep(Gp);
+        RC(bp_g1vec_wrap_device(ctx, H->d, pn, &Hp));
+        T.keep(Hp);
+        size_t lg_out = 0;
+        RC(bp_ipp_create(ctx, t, Q, ippin[2], ippin[3], Gp, Hp, ippin[0], ippin[1], Lp, Rp, &lg_out, ab, ab + 32));   // :567-576
+        return lg_out == lg ? BP_OK : BP_ERR_DEVICE;
+    }
+
+    static int verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                      const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, const uint8_t* r_le32) {
+        Temps T;
+        const int cv = ctx->curve;
+        const size_t pn = padded_len(n), lg = lg_of(pn);
+        const uint8_t* P = proof;
+        const uint8_t* S = proof + 11 * pb;
+        const uint8_t* Lp = S + 96;
+        const uint8_t* Rp = Lp + lg * pb;
+        const uint8_t* ab = Rp + lg * pb;
+        RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // verifier.rs:278
+        RC(bp_transcript_commit_point(t, cv, "A_I1", P + 0 * pb));
+        RC(bp_transcript_commit_point(t, cv, "A_O1", P + 1 * pb));
+        RC(bp_transcript_commit_point(t, cv, "S1", P + 2 * pb));
+        RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));
+        RC(bp_transcript_commit_point(t, cv, "A_I2", P + 3 * pb));
+        RC(bp_transcript_commit_point(t, cv, "A_O2", P + 4 * pb));
+        RC(bp_transcript_commit_point(t, cv, "S2", P + 5 * pb));
+        const Fe<F> y = challenge(t, cv, "y"), z = challenge(t, cv, "z");
+        static const char* const tlabel[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
+        for (int j = 0; j < 5; j++) RC(bp_transcript_commit_point(t, cv, tlabel[j], P + (6 + j) * pb));
+        const Fe<F> u = challenge(t, cv, "u"), x = challenge(t, cv, "x");
+        RC(bp_transcript_commit_scalar(t, cv, "t_x", S));
+        RC(bp_transcript_commit_scalar(t, cv, "t_x_blinding", S + 32));
+        RC(bp_transcript_commit_scalar(t, cv, "e_blinding", S + 64));
+        const Fe<F> wch = challenge(t, cv, "w");
+        uint8_t zle[32], xle[32], ule[32], yile[32], wcle[32];
+        fr_out<F>(z, zle); fr_out<F>(x, xle); fr_out<F>(u, ule);
+        bp_frvec* w[4] = {};
+        RC(bp_r1cs_flattened_constraints(ctx, plan, zle, w, wcle));                                            // :329
+        for (auto* v : w) T.keep(v);
+        const Fe<F> wc = fr_in<F>(wcle), a = fr_in<F>(ab), b = fr_in<F>(ab + 32);
+        const Fe<F> y_inv = fe_inv<F>(y);
+        fr_out<F>(y_inv, yile);
+        bp_frvec *yv = nullptr, *ywr = nullptr;
+        RC(bp_fr_vandermonde(ctx, yile, n, &yv));
+        T.keep(yv);
+        RC(bp_fr_hadamard(ctx, w[1], yv, &ywr));
+        T.keep(ywr);
+        uint8_t dle[32];
+        RC(bp_fr_inner_product(ctx, ywr, 0, w[0], 0, n, dle));                                                 // delta, :344-352
+        const Fe<F> delta = fr_in<F>(dle);
+        std::vector<uint8_t> usq(lg * 32 + 32), uisq(lg * 32 + 32);
+        bp_frvec *g_sc = nullptr, *h_sc = nullptr;
+        RC(bp_r1cs_verifier_scalars(ctx, t, Lp, Rp, lg, pn, n, w[0], w[1], w[2], yile, xle, ule, ab, ab + 32, usq.data(), uisq.data(), &g_sc, &h_sc));   // :354-390
+        T.keep(g_sc);
+        T.keep(h_sc);
+        const Fe<F> r = fr_in<F>(r_le32);                                                                      // :392
+        const Fe<F> x2 = fe_sqr(x), x3 = fe_mul(x2, x);
+        const Fe<F> tx = fr_in<F>(S), txb = fr_in<F>(S + 32), eb = fr_in<F>(S + 64);
+        // scalars and points in the reference's order (:409-446): A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1.. | g h | G | H | L | R
+        const size_t head = 6 + m + 5 + 2, total = head + 2 * pn + 2 * lg;
+        bp_frvec* sc = nullptr;
+        bp_g1vec* pts = nullptr;
+        RC(bp_frvec_alloc(ctx, total, &sc));
+        T.keep(sc);
+        RC(bp_g1vec_alloc(ctx, total, &pts));
+        T.keep(pts);
+        std::vector<uint8_t> hs(6 * 32), ts(7 * 32);
+        const Fe<F> hv[6] = {x, x2, x3, fe_mul(u, x), fe_mul(u, x2), fe_mul(u, x3)};
+        for (int k = 0; k < 6; k++) fr_out<F>(hv[k], hs.data() + 32 * k);
+        Fe<F> rx = fe_mul(r, x);
+        fr_out<F>(rx, ts.data());                                                                              // r x
+        Fe<F> acc = fe_mul(r, x3);
+        for (int k = 1; k < 5; k++) { fr_out<F>(acc, ts.data() + 32 * k); acc = fe_mul(acc, x); }              // r x^3 .. r x^6
+        const Fe<F> wg = fe_add(fe_mul(wch, fe_sub(tx, fe_mul(a, b))), fe_mul(r, fe_sub(fe_mul(x2, fe_add(wc, delta)), tx)));   // :422
+        const Fe<F> ph = fe_neg(fe_add(eb, fe_mul(r, txb)));                                                   // :425
+        fr_out<F>(wg, ts.data() + 5 * 32);
+        fr_out<F>(ph, ts.data() + 6 * 32);
+        bp_frvec *d_hs = nullptr, *d_ts = nullptr;
+        RC(upload_scalars(ctx, T, hs, &d_hs));
+        RC(upload_scalars(ctx, T, ts, &d_ts));
+        RC(bp_frvec_copy(ctx, sc, 0, d_hs, 0, 6));
+        if (m) {
+            uint8_t rx2[32];
+            fr_out<F>(fe_mul(r, x2), rx2);
+            bp_frvec* wvs = nullptr;
+            RC(bp_fr_scaled_by(ctx, w[3], rx2, &wvs));                                                         // :416
+            T.keep(wvs);
+            RC(bp_frvec_copy(ctx, sc, 6, wvs, 0, m));
+        }
+        RC(bp_frvec_copy(ctx, sc, 6 + m, d_ts, 0, 7));
+        RC(bp_frvec_copy(ctx, sc, head, g_sc, 0, pn));
+        RC(bp_frvec_copy(ctx, sc, head + pn, h_sc, 0, pn));
+        if (lg) {
+            std::vector<uint8_t> us(2 * lg * 32);
+            memcpy(us.data(), usq.data(), lg * 32);
+            memcpy(us.data() + lg * 32, uisq.data(), lg * 32);
+            bp_frvec* d_us = nullptr;
+            RC(upload_scalars(ctx, T, us, &d_us));
+            RC(bp_frvec_copy(ctx, sc, head + 2 * pn, d_us, 0, 2 * lg));
+        }
+        std::vector<uint8_t> hp(head * pb);
+        memcpy(hp.data(), P, 6 * pb);
+        if (m) memcpy(hp.data() + 6 * pb, V_le, m * pb);
+        memcpy(hp.data() + (6 + m) * pb, P + 6 * pb, 5 * pb);
+        memcpy(hp.data() + (11 + m) * pb, g_le, pb);
+        memcpy(hp.data() + (12 + m) * pb, h_le, pb);
+        bp_g1vec* d_hp = nullptr;
+        RC(bp_g1vec_upload(ctx, hp.data(), head, BP_FMT_LE, &d_hp));
+        T.keep(d_hp);
+        hipStream_t s = ctx->stream;
+        HIPCHK(hipMemcpyAsync(pts->d, d_hp->d, head * row, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + head * row, G->d, pn * row, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (head + pn) * row, H->d, pn * row, hipMemcpyDeviceToDevice, s));
+        if (lg) {
+            std::vector<uint8_t> lr(2 * lg * pb);
+            memcpy(lr.data(), Lp, lg * pb);
+            memcpy(lr.data() + lg * pb, Rp, lg * pb);
+            bp_g1vec* d_lr = nullptr;
+            RC(bp_g1vec_upload(ctx, lr.data(), 2 * lg, BP_FMT_LE, &d_lr));
+            T.keep(d_lr);
+            HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (head + 2 * pn) * row, d_lr->d, 2 * lg * row, hipMemcpyDeviceToDevice, s));
+        }
+        uint8_t res[pb];
+        RC(bp_msm_g1(ctx, pts, sc, res));                                                                      // :448
+        for (size_t k = 0; k < pb; k++) if (res[k]) return BP_ERR_VERIFY;                                       // !res.is_identity(), :449-451
+        return BP_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+size_t bp_r1cs_proof_bytes(int curve_id, size_t n) {
+    if (!curve_ok(curve_id) || n == 0) return 0;
+    return curve_id == BP_CURVE_BLS12_381 ? R1cs<Bls381>::proof_bytes(n) : R1cs<Bn254>::proof_bytes(n);
+}
+
+int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                  const uint8_t* h_le, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O, const bp_frvec* v_blinding, const bp_frvec* s_L,
+                  const bp_frvec* s_R, const uint8_t* blindings_le32, uint8_t* proof_out, size_t proof_cap) {
+    if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || !a_L || !a_R || !a_O || !s_L || !s_R || !blindings_le32 || !proof_out) return BP_ERR_ARG;
+    const size_t n = a_L->n;
+    if (n == 0 || a_R->n != n || a_O->n != n || s_L->n != n || s_R->n != n) return BP_ERR_LENGTH;
+    size_t pn = 1;
+    while (pn < n) pn <<= 1;
+    if (G->n < pn || H->n < pn) return BP_ERR_LENGTH;                      // R1CSError::InvalidGeneratorsLength, prover.rs:333,382
+    if (proof_cap < bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_LENGTH;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::prove(ctx, t, plan, G, H, g_le, h_le, a_L, a_R, a_O, v_blinding, s_L, s_R, blindings_le32, proof_out);
+    return R1cs<Bn254>::prove(ctx, t, plan, G, H, g_le, h_le, a_L, a_R, a_O, v_blinding, s_L, s_R, blindings_le32, proof_out);
+}
+
+int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                   const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, size_t proof_len, const uint8_t* r_le32) {
+    if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || (m && !V_le) || !proof || !r_le32 || n == 0) return BP_ERR_ARG;
+    if (proof_len != bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_VERIFY;
+    size_t pn = 1;
+    while (pn < n) pn <<= 1;
+    if (G->n < pn || H->n < pn) return BP_ERR_LENGTH;                      // verifier.rs:296-298
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
+    return R1cs<Bn254>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
+}
+
+}  // extern "C"

@@ -8,6 +8,9 @@ MSMs over resident [G | H | h], `flattened_constraints` (R1CSPlan), the l/r poly
 the inner-product argument, and the verifier's MSM.  The constraint-system builder and the gadgets are NOT mirrored
 (out of scope): a circuit arrives as flat term lists.
 
+The same orchestration exists as C++ inside the library (csrc/bp_capi_r1cs.hip: bp_r1cs_prove / bp_r1cs_verify, one call each);
+the tests require both to produce the same proof bytes, and the benchmarks time the library calls.
+
 There are no reference vectors for a whole proof (the reference cannot run in this image), so what the tests establish is
 consistency -- honest proofs verify, modified ones do not -- on top of the per-kernel parity tests.
 """

@@ -273,6 +273,22 @@ int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constr
 int bp_r1cs_plan_free(bp_r1cs_plan* plan);
 /* out = {wL, wR, wO, wV} (new vectors); wc_le32 may be NULL (the prover does not need the constant, prover.rs:176-178). */
 int bp_r1cs_flattened_constraints(bp_ctx* ctx, const bp_r1cs_plan* plan, const uint8_t* z_le32, bp_frvec* out[4], uint8_t* wc_le32);
+/* The two callers of everything above, as host orchestration inside the library (bp_capi_r1cs.hip, written against this
+ * header): `Prover::prove` (src/r1cs/prover.rs:323-560) and `Verifier::verify` (src/r1cs/verifier.rs:265-452) for
+ * single-phase constraint systems (no randomised second phase: A_I2 = A_O2 = S2 = identity).  The transcript must already
+ * hold what `Prover::new` / `commit` put there (r1cs_domain_sep, one commit_point("V") per committed value).
+ * Proof layout (bp_r1cs_proof_bytes): A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6 (points, x || y LE) | t_x t_x_blinding
+ * e_blinding | L[lg] R[lg] | a b, lg = log2 of the padded gate count.
+ * prove: a_L, a_R, a_O, s_L, s_R of length n (gates), v_blinding of length m (may be NULL when m = 0); blindings_le32 = eight
+ * scalars i, o, s, t1, t3, t4, t5, t6 (the reference draws them from its RNG, prover.rs:337-341,490-494).  G, H need at
+ * least padded-n points (BP_ERR_LENGTH = R1CSError::InvalidGeneratorsLength).
+ * verify: r_le32 = the verifier's random weight (verifier.rs:392); BP_ERR_VERIFY if the combined MSM is not the identity. */
+size_t bp_r1cs_proof_bytes(int curve_id, size_t n);
+int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                  const uint8_t* h_le, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O, const bp_frvec* v_blinding, const bp_frvec* s_L,
+                  const bp_frvec* s_R, const uint8_t* blindings_le32, uint8_t* proof_out, size_t proof_cap);
+int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                   const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, size_t proof_len, const uint8_t* r_le32);
 /* Prover, src/r1cs/prover.rs:465-486.  in = {a_L, a_R, a_O, s_L, s_R, wL, wR, wO} (equal lengths n; wL.. are the
  * flattened constraints, computed on the host); out = {l1, l2, l3, r0, r1, r3}: the non-zero coefficient vectors of
  * l(X) = l1 X + l2 X^2 + l3 X^3 and r(X) = r0 + r1 X + r3 X^3 (feed bp_vecpoly3_special_inner_product / bp_vecpoly_eval). */

@@ -14,12 +14,12 @@ GCC_ASAN=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)
 export PYTHONMALLOC=malloc ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 ( cd "$ROOT" && LD_PRELOAD=$GCC_ASAN BP_ORACLE_SO="$OUT/liboracle.so" python -m pytest tests/test_oracle_golden.py -x -q )
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-for f in bp_capi bp_capi_ipp bp_capi_hash; do
+for f in bp_capi bp_capi_ipp bp_capi_hash bp_capi_r1cs; do
     "$HIPCC" --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer \
         -c -o "$OUT/$f.o" "$ROOT/bulletproofs-amcl_amd/csrc/$f.hip" &
 done
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o "$OUT/libbpmsm.so" "$OUT"/bp_capi.o "$OUT"/bp_capi_ipp.o "$OUT"/bp_capi_hash.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o "$OUT/libbpmsm.so" "$OUT"/bp_capi.o "$OUT"/bp_capi_ipp.o "$OUT"/bp_capi_hash.o "$OUT"/bp_capi_r1cs.o
 CLANG_ASAN=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 ( cd "$ROOT" && LD_PRELOAD=$CLANG_ASAN BPMSM_SO="$OUT/libbpmsm.so" python -m pytest tests/test_capi_cpu.py tests/test_host_cpu.py -x -q -m "not gpu" )
 echo "sanitize_cpu: clean"

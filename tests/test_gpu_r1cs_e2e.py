@@ -61,14 +61,35 @@ def run_prove(bp, R1, ctx, gens, cons, n, m, aL, aR, aO, v, v_blinding, rng):
     blindings = {k: rng.randrange(r) for k in ("i", "o", "s", "t1", "t3", "t4", "t5", "t6")}
     sL, sR = [rng.randrange(r) for _ in range(n)], [rng.randrange(r) for _ in range(n)]
     proof = R1.prove(ctx, gens, plan, R1.start_transcript(ctx, b"R1CS e2e", V), dev(aL), dev(aR), dev(aO), dev(v_blinding), dev(sL), dev(sR), blindings)
+    # the same orchestration as ONE library call (bp_r1cs_prove, C++ inside libbpmsm.so): identical proof bytes
+    order = ("i", "o", "s", "t1", "t3", "t4", "t5", "t6")
+    raw = bp.r1cs_prove(ctx, R1.start_transcript(ctx, b"R1CS e2e", V), plan, gens.G, gens.H, gens.g, gens.h, dev(aL), dev(aR), dev(aO),
+                        dev(v_blinding) if m else None, dev(sL), dev(sR), b"".join(le(blindings[k]) for k in order))
+    assert raw == flatten_proof(ctx, proof)
     plan.free()
     return V, proof
+
+
+def flatten_proof(ctx, proof):
+    """the byte layout of bp_r1cs_prove (include/bpmsm.h)"""
+    ident = bytes(ctx.point_bytes)
+    ipp = proof["ipp"]
+    return (proof["A_I1"] + proof["A_O1"] + proof["S1"] + ident * 3 + b"".join(proof["T"][k] for k in (1, 3, 4, 5, 6))
+            + le(proof["t_x"]) + le(proof["t_x_blinding"]) + le(proof["e_blinding"]) + ipp.L + ipp.R + ipp.a + ipp.b)
 
 
 def run_verify(bp, R1, ctx, gens, cons, n, V, proof, rng):
     terms = [(q, k, i, c) for q, ts in enumerate(cons) for k, i, c in ts]
     plan = bp.R1CSPlan(ctx, terms, len(cons), n, len(V))
     ok = R1.verify(ctx, gens, plan, R1.start_transcript(ctx, b"R1CS e2e", V), V, proof, r_weight=rng.randrange(ctx.r))
+    # ... and the library's verifier (bp_r1cs_verify) must reach the same verdict on the same proof
+    try:
+        bp.r1cs_verify(ctx, R1.start_transcript(ctx, b"R1CS e2e", V), plan, gens.G, gens.H, gens.g, gens.h, b"".join(V), n, flatten_proof(ctx, proof),
+                       le(rng.randrange(ctx.r)))
+        ok_lib = True
+    except bp.VerificationError:
+        ok_lib = False
+    assert ok_lib == ok
     plan.free()
     return ok
 
