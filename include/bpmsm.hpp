@@ -246,4 +246,67 @@ struct IPP {
     }
 };
 
+// ---- R1CS layer: the callers of the hot path (reference src/r1cs/prover.rs, src/r1cs/verifier.rs) ------------------------
+// A circuit arrives as flat terms (the constraint-system builder and the gadgets are not mirrored).
+struct Term { uint32_t constraint; uint8_t kind; uint32_t index; Bytes coeff_le32; };   // kind = BP_VAR_*
+
+class R1CSPlan {   // the terms regrouped once per circuit for flattened_constraints (prover.rs:142-184, verifier.rs:149-193)
+public:
+    R1CSPlan(Context& ctx, const std::vector<Term>& terms, size_t n_constraints, size_t n, size_t m) : n_(n), m_(m) {
+        std::vector<uint32_t> q(terms.size() + 1), idx(terms.size() + 1);
+        std::vector<uint8_t> kind(terms.size() + 1), coeff(32 * terms.size() + 32);
+        for (size_t t = 0; t < terms.size(); t++) {
+            q[t] = terms[t].constraint; kind[t] = terms[t].kind; idx[t] = terms[t].index;
+            for (int k = 0; k < 32; k++) coeff[32 * t + k] = terms[t].coeff_le32[k];
+        }
+        check(bp_r1cs_plan_create(ctx.handle(), terms.size(), q.data(), kind.data(), idx.data(), coeff.data(), n_constraints, n, m, &h_), "bp_r1cs_plan_create");
+    }
+    R1CSPlan(const R1CSPlan&) = delete;
+    ~R1CSPlan() { bp_r1cs_plan_free(h_); }
+    bp_r1cs_plan* handle() const { return h_; }
+    size_t n() const { return n_; }
+    size_t m() const { return m_; }
+
+private:
+    bp_r1cs_plan* h_ = nullptr;
+    size_t n_, m_;
+};
+
+namespace r1cs {
+
+// Prover::commit for all values at once: [v_j g + r_j h]  (prover.rs:118-127; batched commit_to_field_element)
+inline Bytes commit(Context& ctx, const Bytes& g, const Bytes& h, const FieldElementVector& v, const FieldElementVector& blinding) {
+    bp_g1vec* out = nullptr;
+    check(bp_g1vec_commit_pairs(ctx.handle(), g.data(), h.data(), v.handle(), blinding.handle(), &out), "bp_g1vec_commit_pairs");
+    return G1Vector(ctx, out).to_bytes();
+}
+
+// Prover::new + commit on the transcript side: r1cs_domain_sep, then one commit_point("V") per commitment
+inline void start_transcript(Context& ctx, Transcript& t, const Bytes& V) {
+    t.append_message("dom-sep", Bytes{'r', '1', 'c', 's', ' ', 'v', '1'});
+    for (size_t j = 0; j * ctx.point_bytes() < V.size(); j++)
+        t.commit_point(ctx.curve(), "V", Bytes(V.begin() + j * ctx.point_bytes(), V.begin() + (j + 1) * ctx.point_bytes()));
+}
+
+// Prover::prove (prover.rs:323-560), single phase.  blindings = i, o, s, t1, t3, t4, t5, t6 (8 x 32 bytes).
+inline Bytes prove(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Vector& G, const G1Vector& H, const Bytes& g, const Bytes& h,
+                   const FieldElementVector& a_L, const FieldElementVector& a_R, const FieldElementVector& a_O, const FieldElementVector* v_blinding,
+                   const FieldElementVector& s_L, const FieldElementVector& s_R, const Bytes& blindings) {
+    Bytes proof(bp_r1cs_proof_bytes(ctx.curve(), a_L.len()));
+    check(bp_r1cs_prove(ctx.handle(), t.handle(), plan.handle(), G.handle(), H.handle(), g.data(), h.data(), a_L.handle(), a_R.handle(), a_O.handle(),
+                        v_blinding ? v_blinding->handle() : nullptr, s_L.handle(), s_R.handle(), blindings.data(), proof.data(), proof.size()),
+          "bp_r1cs_prove");
+    return proof;
+}
+
+// Verifier::verify (verifier.rs:265-452): returns on success, throws VerificationError otherwise.
+inline void verify(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Vector& G, const G1Vector& H, const Bytes& g, const Bytes& h, const Bytes& V,
+                   const Bytes& proof, const Bytes& r_weight_le32) {
+    check(bp_r1cs_verify(ctx.handle(), t.handle(), plan.handle(), G.handle(), H.handle(), g.data(), h.data(), V.empty() ? nullptr : V.data(), plan.n(),
+                         V.size() / ctx.point_bytes(), proof.data(), proof.size(), r_weight_le32.data()),
+          "bp_r1cs_verify");
+}
+
+}  // namespace r1cs
+
 }  // namespace bp

@@ -73,6 +73,49 @@ static int gpu_mode(int curve) {
         bp::IPP::verify_batch(ctx, n, G_factors, H_factors, Gh, Hh, {{&ta, &P2, &Qh, &proof2}, {&tb, &P2, &Q3, &proof3}}, weights);   // wrong commitment
         printf("bad batch accepted\n"); return 1;
     } catch (const bp::VerificationError&) {}
+    if (curve == BP_CURVE_BLS12_381) {
+        // R1CS layer through the mirror: two multiplication gates (3 * 5 = 15, 2 * 7 = 14), one committed value v = 15 and the
+        // constraint a_O[0] - V_0 = 0 (plus a trivially true one); bp_r1cs_prove / bp_r1cs_verify (prover.rs:323-560, verifier.rs:265-452)
+        const bp::Bytes minus_one = {0x00, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
+                                     0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73};   // r - 1
+        std::vector<bp::Term> terms = {{0, BP_VAR_MUL_OUTPUT, 0, scalar(1)}, {0, BP_VAR_COMMITTED, 0, minus_one},
+                                       {1, BP_VAR_MUL_LEFT, 1, scalar(1)}, {1, BP_VAR_MUL_LEFT, 1, minus_one}};
+        bp::R1CSPlan plan(ctx, terms, 2, 2, 1);
+        bp::Bytes gq = bp::G1Vector::from_msg_hash(ctx, {"g"}).to_bytes(), hq = bp::G1Vector::from_msg_hash(ctx, {"h"}).to_bytes();
+        bp::G1Vector GG = bp::G1Vector::get_generators(ctx, "G", 2), HH = bp::G1Vector::get_generators(ctx, "H", 2);
+        bp::FieldElementVector aL(ctx, ints({3, 2})), aR(ctx, ints({5, 7})), aO(ctx, ints({15, 14})), vv(ctx, ints({15})), vb(ctx, ints({424242}));
+        bp::FieldElementVector sL(ctx, ints({1001, 1002})), sR(ctx, ints({2001, 2002}));
+        bp::Bytes V = bp::r1cs::commit(ctx, gq, hq, vv, vb);
+        bp::Bytes blindings = ints({11, 12, 13, 14, 15, 16, 17, 18});
+        bp::Transcript tp("cpp r1cs");
+        bp::r1cs::start_transcript(ctx, tp, V);
+        bp::Bytes rproof = bp::r1cs::prove(ctx, tp, plan, GG, HH, gq, hq, aL, aR, aO, &vb, sL, sR, blindings);
+        if (rproof.size() != bp_r1cs_proof_bytes(curve, 2)) { printf("wrong r1cs proof size\n"); return 1; }
+        {
+            bp::Transcript tv("cpp r1cs");
+            bp::r1cs::start_transcript(ctx, tv, V);
+            bp::r1cs::verify(ctx, tv, plan, GG, HH, gq, hq, V, rproof, scalar(0x5eed5eed));
+        }
+        try {
+            bp::Bytes badp = rproof;
+            badp[11 * ctx.point_bytes()] ^= 1;                   // t_x
+            bp::Transcript tv("cpp r1cs");
+            bp::r1cs::start_transcript(ctx, tv, V);
+            bp::r1cs::verify(ctx, tv, plan, GG, HH, gq, hq, V, badp, scalar(0x5eed5eed));
+            printf("tampered r1cs proof accepted\n"); return 1;
+        } catch (const bp::VerificationError&) {}
+        try {                                                    // a witness that breaks the gate: 3 * 5 != 16
+            bp::FieldElementVector aObad(ctx, ints({16, 14})), v16(ctx, ints({16}));
+            bp::Bytes V16 = bp::r1cs::commit(ctx, gq, hq, v16, vb);
+            bp::Transcript tp2("cpp r1cs");
+            bp::r1cs::start_transcript(ctx, tp2, V16);
+            bp::Bytes p2 = bp::r1cs::prove(ctx, tp2, plan, GG, HH, gq, hq, aL, aR, aObad, &vb, sL, sR, blindings);
+            bp::Transcript tv("cpp r1cs");
+            bp::r1cs::start_transcript(ctx, tv, V16);
+            bp::r1cs::verify(ctx, tv, plan, GG, HH, gq, hq, V16, p2, scalar(77));
+            printf("unsatisfied circuit accepted\n"); return 1;
+        } catch (const bp::VerificationError&) {}
+    }
     printf("cpp gpu ok curve=%d a=%s\n", curve, hex(proof.a).c_str());
     return 0;
 }
