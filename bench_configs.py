@@ -164,19 +164,23 @@ def cfg5():
     return {"config": "cfg5: BN254 (AMCL/Nogami) 2^20 MSM + IPP n=2^12", "msm_ms": t * 1e3, "msm_scalar_muls_per_s": n / t, "msm_ok": bool(got == want), "ipp": ipp}
 
 
-def bound_check_chain(r, checks, bits, rng):
+def bound_check_chain(r, checks, bits, rng, triples=None):
     """The circuit of BASELINE config 3: `checks` bound checks (src/r1cs/gadgets/bound_check.rs:12-40) of `bits`-bit numbers,
     each = 3 committed values (v, a = v - min, b = max - v), 3 linear constraints and two positive_no gadgets
     (helper_constraints/positive_no.rs:8-42: per bit one multiplier (1 - bit, bit, 0), `o = 0`, `a + b - 1 = 0`, and
     `-x + sum 2^i b_i = 0`).  1024 checks of 32 bits: 65 536 gates, 136 192 constraints, m = 3 072.
+    triples: explicit (val, min, max) per check instead of random ones (tests compare this generator with the oracle's gadgets).
     Returns (terms, n_constraints, aL, aR, aO, v) with terms = (constraint, kind, index, coeff)."""
     L, R_, O_, C, ONE = 0, 1, 2, 3, 4
     terms, aL, aR, v = [], [], [], []
     q = 0
     for c in range(checks):
-        lo = int(rng.integers(0, 1 << 20))
-        hi = lo + (1 << bits) - 1 - int(rng.integers(0, 1 << 10))
-        val = int(rng.integers(lo, hi + 1))
+        if triples is not None:
+            val, lo, hi = triples[c]
+        else:
+            lo = int(rng.integers(0, 1 << 20))
+            hi = lo + (1 << bits) - 1 - int(rng.integers(0, 1 << 10))
+            val = int(rng.integers(lo, hi + 1))
         a, b = val - lo, hi - val
         iv, ia, ib = 3 * c, 3 * c + 1, 3 * c + 2
         v += [val, a, b]

@@ -256,10 +256,119 @@ def gen_hash_to_g1():
     return out
 
 
+def gen_r1cs():
+    """Whole R1CS proofs from pyref.r1cs_prove / r1cs_verify (restated from src/r1cs/prover.rs:322-593, verifier.rs:267-457):
+    the reference's own test shapes at small sizes, with the randomness the reference draws from its RNG fixed by the seed.
+      factors_2          tests/r1cs.rs:16-70   (two p * q = r statements via `multiply`, 8 generators)
+      bound_check_3bit   src/r1cs/gadgets/bound_check.rs:188-230 shrunk to 3 bits (6 gates -> padded to 8)
+      bound_chain_2x4    tests/multiple_constraint_systems.rs:25-97 shape: two chained bound checks of 4 bits in ONE prover
+                         (16 gates: no padding) -- BASELINE config 3 is this with 1024 checks of 32 bits
+      one_gate           a single multiplier (padded_n = 1: the inner-product argument has zero rounds)
+      no_commitments     m = 0
+    Each case: the circuit as flat terms, generators, witness, randomness, commitments V, the proof bytes (C-ABI layout) and the
+    scalars of the verifier's single MSM for a fixed verifier weight r."""
+    out = {}
+    for c in (R.BLS12_381, R.BN254):
+        rng = R.SplitMix64(SEED + 900 + c.curve_id)
+        g, hh = R.g1_from_msg_hash(c, b"g"), R.g1_from_msg_hash(c, b"h")
+        cases = []
+
+        def build_factors(cs, comms):
+            outs = []
+            for (p_, q_, r_) in ((17, 19, 323), (7, 5, 35)):
+                if comms is None:
+                    Vp, vp = cs.commit(p_, rng.scalar(c))
+                    Vq, vq = cs.commit(q_, rng.scalar(c))
+                    outs += [Vp, Vq]
+                else:
+                    vp, vq = cs.commit(comms.pop(0)), cs.commit(comms.pop(0))
+                _, _, o = cs.multiply([(vp, 1)], [(vq, 1)])
+                cs.constrain(R.lc_sub(c, [(o, 1)], R.lc_scalar(c, r_)))
+            return outs
+
+        def build_bound3(cs, comms):
+            if comms is None:
+                return R.prove_bounded_num(cs, 13, rng.scalar(c), 10, 17, 3, rng.scalar(c), rng.scalar(c))
+            R.verify_bounded_num(cs, 10, 17, 3, comms)
+
+        def build_chain(cs, comms):
+            outs = []
+            for val, lo, hi in ((9, 3, 18), (200, 190, 205)):
+                if comms is None:
+                    outs += R.prove_bounded_num(cs, val, rng.scalar(c), lo, hi, 4, rng.scalar(c), rng.scalar(c))
+                else:
+                    R.verify_bounded_num(cs, lo, hi, 4, [comms.pop(0) for _ in range(3)])
+            return outs
+
+        def build_one_gate(cs, comms):
+            if comms is None:
+                Vr, vr = cs.commit(12, rng.scalar(c))
+                a, b, o = cs.allocate_multiplier(3, 4)
+                outs = [Vr]
+            else:
+                vr = cs.commit(comms.pop(0))
+                a, b, o = cs.allocate_multiplier()
+                outs = None
+            cs.constrain(R.lc_sub(c, [(o, 1)], [(vr, 1)]))
+            cs.constrain(R.lc_sub(c, [(a, 1)], R.lc_scalar(c, 3)))
+            return outs
+
+        def build_no_commitments(cs, comms):
+            vals = ((2, 3), (5, 7), (11, 13))
+            for l_, r_ in vals:
+                a, b, o = cs.allocate_multiplier(l_, r_) if comms is None else cs.allocate_multiplier()
+                cs.constrain(R.lc_sub(c, [(o, 1)], R.lc_scalar(c, l_ * r_)))
+                cs.constrain(R.lc_sub(c, [(a, 2), (b, c.r - 1)], R.lc_scalar(c, 2 * l_ - r_)))
+            return []
+
+        for name, label, ngens, build in (("factors_2", b"Factors", 8, build_factors), ("bound_check_3bit", b"BoundsTest", 8, build_bound3),
+                                          ("bound_chain_2x4", b"BoundsChain", 16, build_chain), ("one_gate", b"OneGate", 2, build_one_gate),
+                                          ("no_commitments", b"NoComm", 4, build_no_commitments)):
+            G, H = R.get_generators(c, "G", ngens), R.get_generators(c, "H", ngens)
+            prover = R.R1CSProver(c, g, hh, R.Transcript(label))
+            V = build(prover, None)
+            n, m = len(prover.aL), len(prover.v)
+            rand = {"i_blinding1": rng.scalar(c), "o_blinding1": rng.scalar(c), "s_blinding1": rng.scalar(c),
+                    "s_L1": [rng.scalar(c) for _ in range(n)], "s_R1": [rng.scalar(c) for _ in range(n)]}
+            for k in (1, 3, 4, 5, 6):
+                rand["t_%d_blinding" % k] = rng.scalar(c)
+            assert all(prover.eval(lc) == 0 for lc in prover.constraints), "fixture circuit is not satisfied"
+            proof = R.r1cs_prove(prover, G, H, rand)
+            rv = rng.scalar(c)
+            ver = R.R1CSVerifier(c, R.Transcript(label))
+            build(ver, list(V))
+            assert ver.constraints == prover.constraints and ver.num_vars == n
+            sc, pts = R.r1cs_verifier_msm(ver, proof, g, hh, G, H, rv)
+            assert c.msm(sc, pts) is None, "fixture proof does not verify"
+            bad = dict(proof, t_x=(proof["t_x"] + 1) % c.r)
+            ver2 = R.R1CSVerifier(c, R.Transcript(label))
+            build(ver2, list(V))
+            assert not R.r1cs_verify(ver2, bad, g, hh, G, H, rv)
+            terms = R.constraints_to_terms(prover.constraints)
+            cases.append({
+                "name": name, "label": h(label), "n": n, "m": m, "n_constraints": len(prover.constraints), "n_generators": ngens,
+                "terms": [[q, k, i, fr_le(c, cf)] for q, k, i, cf in terms],
+                "g": pt_le(c, g), "h": pt_le(c, hh), "G": [pt_le(c, P) for P in G], "H": [pt_le(c, P) for P in H],
+                "V": [pt_le(c, P) for P in V],
+                "a_L": [fr_le(c, x) for x in prover.aL], "a_R": [fr_le(c, x) for x in prover.aR], "a_O": [fr_le(c, x) for x in prover.aO],
+                "v": [fr_le(c, x) for x in prover.v], "v_blinding": [fr_le(c, x) for x in prover.v_blinding],
+                "s_L": [fr_le(c, x) for x in rand["s_L1"]], "s_R": [fr_le(c, x) for x in rand["s_R1"]],
+                "blindings": [fr_le(c, rand[k]) for k in ("i_blinding1", "o_blinding1", "s_blinding1", "t_1_blinding", "t_3_blinding",
+                                                          "t_4_blinding", "t_5_blinding", "t_6_blinding")],
+                "proof": h(R.r1cs_proof_to_le(c, proof)),
+                "verifier_r": fr_le(c, rv), "verifier_msm_scalars": [fr_le(c, x) for x in sc],
+            })
+            print("  r1cs", c.name, name, "gates", n, file=sys.stderr)
+        out[c.name] = cases
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("curves", gen_curves), ("field", gen_field), ("g1", gen_g1), ("merlin", gen_merlin),
-                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1)):
+                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1), ("r1cs", gen_r1cs)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue                                                   # python3 oracle/gen_golden.py r1cs  -> only that file
         print("generating", name, file=sys.stderr)
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=0, sort_keys=True)

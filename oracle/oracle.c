@@ -8,6 +8,26 @@
 #include <string.h>
 #include <time.h>
 
+/* ---------------- threads ----------------
+ * orc_set_threads(k): worker threads used by the MSMs inside the IPP / R1CS restatements and by the IPP fold loop
+ * (each i of src/ipp.rs:115-130,181-188 is independent).  The reference is single-threaded; threads only shorten the
+ * checker's run time, results do not depend on k. */
+static int orc_threads = 1;
+typedef struct { void (*fn)(size_t, size_t, void*); void* arg; size_t lo, hi; } orc_pf_job;
+static void* orc_pf_worker(void* p) { orc_pf_job* j = (orc_pf_job*)p; j->fn(j->lo, j->hi, j->arg); return NULL; }
+static void orc_parallel_for(size_t n, void (*fn)(size_t, size_t, void*), void* arg) {
+    int k = orc_threads;
+    if (k > 64) k = 64;
+    if ((size_t)k > n / 4) k = (int)(n / 4);
+    if (k <= 1) { fn(0, n, arg); return; }
+    pthread_t th[64]; orc_pf_job jobs[64];
+    for (int t = 0; t < k; t++) {
+        jobs[t] = (orc_pf_job){fn, arg, n * (size_t)t / k, n * (size_t)(t + 1) / k};
+        pthread_create(&th[t], NULL, orc_pf_worker, &jobs[t]);
+    }
+    for (int t = 0; t < k; t++) pthread_join(th[t], NULL);
+}
+
 /* ---------------- field instances ---------------- */
 #define NL 6
 #define F(x) fp381_##x
@@ -45,6 +65,7 @@
 #define COFACTOR_WORDS {0x8c00aaab0000aaabULL, 0x396c8c005555e156ULL, 0, 0}   /* (x-1)^2/3 */
 #include "orc_curve_tmpl.h"
 #include "orc_ipp_tmpl.h"
+#include "orc_r1cs_tmpl.h"
 #include "orc_api_tmpl.h"
 #undef C
 #undef FP
@@ -67,6 +88,7 @@
 #define COFACTOR_WORDS {1, 0, 0, 0}
 #include "orc_curve_tmpl.h"
 #include "orc_ipp_tmpl.h"
+#include "orc_r1cs_tmpl.h"
 #include "orc_api_tmpl.h"
 #undef C
 #undef FP
@@ -205,4 +227,33 @@ int orc_ipp_verification_scalars(int curve, void* tr, const uint8_t* L, const ui
                                  uint8_t* u_sq, uint8_t* u_inv_sq, uint8_t* s) {
     DISPATCH(bls381_api_verification_scalars((orc_transcript*)tr, L, R, lg_n, n, u_sq, u_inv_sq, s),
              bn254_api_verification_scalars((orc_transcript*)tr, L, R, lg_n, n, u_sq, u_inv_sq, s));
+}
+
+void orc_set_threads(int k) { orc_threads = k < 1 ? 1 : k; }
+
+int orc_r1cs_prove(int curve, void* tr, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                   const uint8_t* coeff, size_t n_constraints, size_t n, size_t m, const uint8_t* g, const uint8_t* h, const uint8_t* G,
+                   const uint8_t* H, size_t ngens, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* v_blinding,
+                   const uint8_t* sL, const uint8_t* sR, const uint8_t* blindings, uint8_t* proof_out) {
+    DISPATCH(bls381_api_r1cs_prove((orc_transcript*)tr, n_terms, term_constraint, term_kind, term_index, coeff, n_constraints, n, m, g, h, G, H, ngens, aL, aR,
+                                   aO, v_blinding, sL, sR, blindings, proof_out),
+             bn254_api_r1cs_prove((orc_transcript*)tr, n_terms, term_constraint, term_kind, term_index, coeff, n_constraints, n, m, g, h, G, H, ngens, aL, aR,
+                                  aO, v_blinding, sL, sR, blindings, proof_out));
+}
+int orc_r1cs_verify(int curve, void* tr, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                    const uint8_t* coeff, size_t n_constraints, size_t n, size_t m, const uint8_t* V, const uint8_t* proof, size_t proof_len,
+                    const uint8_t* g, const uint8_t* h, const uint8_t* G, const uint8_t* H, size_t ngens, const uint8_t* rnd) {
+    DISPATCH(bls381_api_r1cs_verify((orc_transcript*)tr, n_terms, term_constraint, term_kind, term_index, coeff, n_constraints, n, m, V, proof, proof_len, g, h,
+                                    G, H, ngens, rnd),
+             bn254_api_r1cs_verify((orc_transcript*)tr, n_terms, term_constraint, term_kind, term_index, coeff, n_constraints, n, m, V, proof, proof_len, g, h,
+                                   G, H, ngens, rnd));
+}
+int orc_r1cs_flattened_constraints(int curve, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                                   const uint8_t* coeff, size_t n_constraints, size_t n, size_t m, const uint8_t* z, uint8_t* wL, uint8_t* wR, uint8_t* wO,
+                                   uint8_t* wV, uint8_t* wc) {
+    DISPATCH(bls381_api_r1cs_flatten(n_terms, term_constraint, term_kind, term_index, coeff, n_constraints, n, m, z, wL, wR, wO, wV, wc),
+             bn254_api_r1cs_flatten(n_terms, term_constraint, term_kind, term_index, coeff, n_constraints, n, m, z, wL, wR, wO, wV, wc));
+}
+int orc_transcript_commit_scalar(int curve, void* t, const char* label, const uint8_t* x) {
+    DISPATCH(bls381_api_commit_scalar((orc_transcript*)t, label, x), bn254_api_commit_scalar((orc_transcript*)t, label, x));
 }

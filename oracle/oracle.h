@@ -65,6 +65,27 @@ int orc_ipp_verify(int curve, void* transcript, size_t n, const uint8_t* G_facto
 /* src/ipp.rs:262-315 */
 int orc_ipp_verification_scalars(int curve, void* transcript, const uint8_t* L, const uint8_t* R, size_t lg_n, size_t n,
                                  uint8_t* u_sq, uint8_t* u_inv_sq, uint8_t* s);
+
+/* worker threads for the MSMs and the fold loop inside orc_ipp_* / orc_r1cs_* (results are independent of k; default 1) */
+void orc_set_threads(int k);
+int orc_transcript_commit_scalar(int curve, void* t, const char* label, const uint8_t* x_le32);
+
+/* R1CS layer, constraint systems without deferred constraints (oracle/orc_r1cs_tmpl.h):
+ *   Prover::prove   src/r1cs/prover.rs:322-593      Verifier::verify   src/r1cs/verifier.rs:267-457
+ * Terms: constraint index, kind (0/1/2 MultiplierLeft/Right/Output, 3 Committed, 4 One), variable index, 32-byte LE coefficient.
+ * The transcript already holds r1cs_domain_sep and one commit_point("V") per committed value.  blindings = i, o, s, t1, t3,
+ * t4, t5, t6.  Proof bytes as include/bpmsm.h lays them out: 11 points | t_x t_x_blinding e_blinding | L[lg] R[lg] | a b.
+ * Return 0 ok / accepted, 1 not enough generators, 2 bad argument, 3 verification failed. */
+int orc_r1cs_prove(int curve, void* transcript, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                   const uint8_t* coeff, size_t n_constraints, size_t n, size_t m, const uint8_t* g, const uint8_t* h, const uint8_t* G,
+                   const uint8_t* H, size_t ngens, const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* v_blinding,
+                   const uint8_t* sL, const uint8_t* sR, const uint8_t* blindings, uint8_t* proof_out);
+int orc_r1cs_verify(int curve, void* transcript, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                    const uint8_t* coeff, size_t n_constraints, size_t n, size_t m, const uint8_t* V, const uint8_t* proof, size_t proof_len,
+                    const uint8_t* g, const uint8_t* h, const uint8_t* G, const uint8_t* H, size_t ngens, const uint8_t* rnd);
+int orc_r1cs_flattened_constraints(int curve, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
+                                   const uint8_t* coeff, size_t n_constraints, size_t n, size_t m, const uint8_t* z, uint8_t* wL, uint8_t* wR, uint8_t* wO,
+                                   uint8_t* wV, uint8_t* wc);
 #ifdef __cplusplus
 }
 #endif

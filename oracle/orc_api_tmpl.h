@@ -194,6 +194,98 @@ static int C(api_commit_point)(orc_transcript* tr, const char* label, const uint
     C(aff_t) a; C(aff_from_le)(&a, p); C(t_commit_point)(tr, label, &a); return 0;
 }
 
+static int C(api_commit_scalar)(orc_transcript* tr, const char* label, const uint8_t* x) {   /* transcript.rs:47-49 */
+    FR(t) v; FR(from_le)(&v, x, FR_LE_BYTES);
+    uint8_t be[MODBYTES]; C(fr_to_be)(be, &v);
+    orc_transcript_append(tr, (const uint8_t*)label, strlen(label), be, MODBYTES);
+    return 0;
+}
+
+/* ---- R1CS (orc_r1cs_tmpl.h).  Proof bytes: 11 points | t_x t_x_blinding e_blinding | L[lg] R[lg] | a b (include/bpmsm.h layout). */
+static int C(r1cs_load_terms)(C(r1cs_terms_t)* cs, size_t n_terms, const uint32_t* con, const uint8_t* kind, const uint32_t* idx, const uint8_t* coeff,
+                              size_t n_constraints, size_t n, size_t m, FR(t)** owned) {
+    for (size_t k = 0; k < n_terms; k++) {
+        if (con[k] >= n_constraints || kind[k] > 4) return 2;
+        if (kind[k] <= 2 && idx[k] >= n) return 2;
+        if (kind[k] == 3 && idx[k] >= m) return 2;
+    }
+    FR(t)* cf = (FR(t)*)malloc((n_terms ? n_terms : 1) * sizeof *cf);
+    C(load_frs)(cf, coeff, n_terms);
+    *owned = cf;
+    *cs = (C(r1cs_terms_t)){n_terms, n_constraints, con, kind, idx, cf};
+    return 0;
+}
+static size_t C(r1cs_lg)(size_t n) { size_t lg = 0; while (((size_t)1 << lg) < n) lg++; return lg; }
+static size_t C(r1cs_proof_bytes)(size_t n) { return 11 * 2 * FP_LE_BYTES + 3 * FR_LE_BYTES + 2 * C(r1cs_lg)(n) * 2 * FP_LE_BYTES + 2 * FR_LE_BYTES; }
+
+static int C(api_r1cs_prove)(orc_transcript* tr, size_t n_terms, const uint32_t* con, const uint8_t* kind, const uint32_t* idx, const uint8_t* coeff,
+                             size_t n_constraints, size_t n, size_t m, const uint8_t* g, const uint8_t* h, const uint8_t* G, const uint8_t* H, size_t ngens,
+                             const uint8_t* aL, const uint8_t* aR, const uint8_t* aO, const uint8_t* vb, const uint8_t* sL, const uint8_t* sR,
+                             const uint8_t* blindings, uint8_t* out) {
+    C(r1cs_terms_t) cs; FR(t)* cf;
+    int rc = C(r1cs_load_terms)(&cs, n_terms, con, kind, idx, coeff, n_constraints, n, m, &cf);
+    if (rc) return rc;
+    C(aff_t) gp, hp; C(aff_from_le)(&gp, g); C(aff_from_le)(&hp, h);
+    C(aff_t)* Gp = (C(aff_t)*)malloc(2 * (ngens ? ngens : 1) * sizeof *Gp); C(aff_t)* Hp = Gp + ngens;
+    C(load_pts)(Gp, G, ngens); C(load_pts)(Hp, H, ngens);
+    FR(t)* wit = (FR(t)*)malloc((5 * n + m + 8 + 1) * sizeof *wit);
+    C(load_frs)(wit, aL, n); C(load_frs)(wit + n, aR, n); C(load_frs)(wit + 2 * n, aO, n); C(load_frs)(wit + 3 * n, sL, n); C(load_frs)(wit + 4 * n, sR, n);
+    C(load_frs)(wit + 5 * n, vb, m); C(load_frs)(wit + 5 * n + m, blindings, 8);
+    C(r1cs_proof_t)* pf = (C(r1cs_proof_t)*)malloc(sizeof *pf);
+    rc = C(r1cs_prove)(tr, &cs, n, m, &gp, &hp, Gp, Hp, ngens, wit, wit + n, wit + 2 * n, wit + 5 * n, wit + 3 * n, wit + 4 * n, wit + 5 * n + m, pf);
+    if (!rc) {
+        uint8_t* o = out;
+        for (int k = 0; k < 11; k++, o += 2 * FP_LE_BYTES) C(aff_to_le)(o, &pf->pts[k]);
+        FR(to_le)(o, &pf->t_x, FR_LE_BYTES); o += FR_LE_BYTES; FR(to_le)(o, &pf->t_x_blinding, FR_LE_BYTES); o += FR_LE_BYTES;
+        FR(to_le)(o, &pf->e_blinding, FR_LE_BYTES); o += FR_LE_BYTES;
+        for (int k = 0; k < pf->lg; k++, o += 2 * FP_LE_BYTES) C(aff_to_le)(o, &pf->L[k]);
+        for (int k = 0; k < pf->lg; k++, o += 2 * FP_LE_BYTES) C(aff_to_le)(o, &pf->R[k]);
+        FR(to_le)(o, &pf->a, FR_LE_BYTES); o += FR_LE_BYTES; FR(to_le)(o, &pf->b, FR_LE_BYTES);
+    }
+    free(cf); free(Gp); free(wit); free(pf);
+    return rc;
+}
+
+static int C(api_r1cs_verify)(orc_transcript* tr, size_t n_terms, const uint32_t* con, const uint8_t* kind, const uint32_t* idx, const uint8_t* coeff,
+                              size_t n_constraints, size_t n, size_t m, const uint8_t* V, const uint8_t* proof, size_t proof_len, const uint8_t* g,
+                              const uint8_t* h, const uint8_t* G, const uint8_t* H, size_t ngens, const uint8_t* rnd) {
+    if (proof_len != C(r1cs_proof_bytes)(n)) return 3;
+    C(r1cs_terms_t) cs; FR(t)* cf;
+    int rc = C(r1cs_load_terms)(&cs, n_terms, con, kind, idx, coeff, n_constraints, n, m, &cf);
+    if (rc) return rc;
+    C(aff_t) gp, hp; C(aff_from_le)(&gp, g); C(aff_from_le)(&hp, h);
+    C(aff_t)* Gp = (C(aff_t)*)malloc((2 * (ngens ? ngens : 1) + m + 1) * sizeof *Gp); C(aff_t)* Hp = Gp + ngens; C(aff_t)* Vp = Hp + ngens;
+    C(load_pts)(Gp, G, ngens); C(load_pts)(Hp, H, ngens); C(load_pts)(Vp, V, m);
+    C(r1cs_proof_t)* pf = (C(r1cs_proof_t)*)malloc(sizeof *pf);
+    const uint8_t* o = proof;
+    pf->lg = (int)C(r1cs_lg)(n);
+    for (int k = 0; k < 11; k++, o += 2 * FP_LE_BYTES) C(aff_from_le)(&pf->pts[k], o);
+    FR(from_le)(&pf->t_x, o, FR_LE_BYTES); o += FR_LE_BYTES; FR(from_le)(&pf->t_x_blinding, o, FR_LE_BYTES); o += FR_LE_BYTES;
+    FR(from_le)(&pf->e_blinding, o, FR_LE_BYTES); o += FR_LE_BYTES;
+    for (int k = 0; k < pf->lg; k++, o += 2 * FP_LE_BYTES) C(aff_from_le)(&pf->L[k], o);
+    for (int k = 0; k < pf->lg; k++, o += 2 * FP_LE_BYTES) C(aff_from_le)(&pf->R[k], o);
+    FR(from_le)(&pf->a, o, FR_LE_BYTES); o += FR_LE_BYTES; FR(from_le)(&pf->b, o, FR_LE_BYTES);
+    FR(t) rr; FR(from_le)(&rr, rnd, FR_LE_BYTES);
+    rc = C(r1cs_verify)(tr, &cs, n, m, Vp, pf, &gp, &hp, Gp, Hp, ngens, &rr);
+    free(cf); free(Gp); free(pf);
+    return rc;
+}
+
+static int C(api_r1cs_flatten)(size_t n_terms, const uint32_t* con, const uint8_t* kind, const uint32_t* idx, const uint8_t* coeff, size_t n_constraints,
+                               size_t n, size_t m, const uint8_t* z, uint8_t* wL, uint8_t* wR, uint8_t* wO, uint8_t* wV, uint8_t* wc) {
+    C(r1cs_terms_t) cs; FR(t)* cf;
+    int rc = C(r1cs_load_terms)(&cs, n_terms, con, kind, idx, coeff, n_constraints, n, m, &cf);
+    if (rc) return rc;
+    FR(t)* w = (FR(t)*)malloc((3 * n + m + 1) * sizeof *w);
+    FR(t) zz, c; FR(from_le)(&zz, z, FR_LE_BYTES);
+    C(r1cs_flatten)(&cs, &zz, n, m, w, w + n, w + 2 * n, w + 3 * n, &c);
+    for (size_t i = 0; i < n; i++) { FR(to_le)(wL + i * FR_LE_BYTES, &w[i], FR_LE_BYTES); FR(to_le)(wR + i * FR_LE_BYTES, &w[n + i], FR_LE_BYTES); FR(to_le)(wO + i * FR_LE_BYTES, &w[2 * n + i], FR_LE_BYTES); }
+    for (size_t j = 0; j < m; j++) FR(to_le)(wV + j * FR_LE_BYTES, &w[3 * n + j], FR_LE_BYTES);
+    FR(to_le)(wc, &c, FR_LE_BYTES);
+    free(cf); free(w);
+    return 0;
+}
+
 /* ---- hash to G1 ---------------------------------------------------------------------------------------------
  * amcl_wrapper `G1::from_msg_hash(msg)` = `GroupG1::mapit(&hash_msg(msg))`, the call behind get_generators
  * (src/utils/mod.rs:16-23).  [UNVERIFIED-RECALL] of amcl `ECP::mapit` / `new_bigint(x, 0)` / `cfp` (crate not vendored):

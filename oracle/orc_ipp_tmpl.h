@@ -14,6 +14,14 @@ static void C(t_commit_point)(orc_transcript* t, const char* label, const C(aff_
     orc_transcript_append(t, (const uint8_t*)label, strlen(label), buf, sizeof buf);
 }
 
+/* FieldElement::to_bytes: MODBYTES big-endian (commit_scalar, transcript.rs:47-49) */
+static void C(fr_to_be)(uint8_t* out, const FR(t)* x) {
+    uint8_t le[FR_LE_BYTES];
+    FR(to_le)(le, x, FR_LE_BYTES);
+    memset(out, 0, MODBYTES);
+    for (int i = 0; i < FR_LE_BYTES; i++) out[MODBYTES - 1 - i] = le[i];
+}
+
 static void C(t_challenge_scalar)(orc_transcript* t, const char* label, FR(t)* out) {        /* transcript.rs:55-60 */
     uint8_t buf[MODBYTES];
     orc_transcript_challenge(t, (const uint8_t*)label, strlen(label), buf, MODBYTES);
@@ -35,7 +43,7 @@ static void C(msm_fr)(C(aff_t)* out, const C(aff_t)* pts, const FR(t)* ks, size_
     uint64_t* raw = (uint64_t*)malloc((n ? n : 1) * FR_NL * 8);
     for (size_t i = 0; i < n; i++) FR(to_raw)(raw + i * FR_NL, &ks[i]);
     C(jac_t) j;
-    if (n <= 32) C(msm_naive)(&j, pts, raw, n); else C(msm_pippenger)(&j, pts, raw, n, 1);
+    if (n <= 32) C(msm_naive)(&j, pts, raw, n); else C(msm_pippenger)(&j, pts, raw, n, orc_threads);
     C(jac_to_aff)(out, &j);
     free(raw);
 }
@@ -48,6 +56,28 @@ static void C(binary_scalar_mul)(C(aff_t)* out, const C(aff_t)* p, const C(aff_t
     C(jac_mul_raw)(&a, k1, p); C(jac_mul_raw)(&b, k2, h);
     C(jac_add)(&a, &a, &b);
     C(jac_to_aff)(out, &a);
+}
+
+/* the fold loop of one round (src/ipp.rs:115-130 first round, :181-188 later rounds) over [lo, hi): independent per i */
+typedef struct { FR(t) *aL, *aR, *bL, *bR; C(aff_t) *GL, *GR, *HL, *HR; const FR(t) *Gf, *Hf; size_t n; int first; FR(t) u, ui; } C(fold_job_t);
+static void C(fold_range)(size_t lo, size_t hi, void* arg) {
+    C(fold_job_t)* j = (C(fold_job_t)*)arg;
+    const size_t n = j->n;
+    const FR(t) *u = &j->u, *ui = &j->ui;
+    for (size_t i = lo; i < hi; i++) {
+        FR(t) t1, t2;
+        FR(mul)(&t1, &j->aL[i], u); FR(mul)(&t2, ui, &j->aR[i]); FR(add)(&j->aL[i], &t1, &t2);
+        FR(mul)(&t1, &j->bL[i], ui); FR(mul)(&t2, u, &j->bR[i]); FR(add)(&j->bL[i], &t1, &t2);
+        if (j->first) {
+            FR(mul)(&t1, ui, &j->Gf[i]); FR(mul)(&t2, u, &j->Gf[n + i]);
+            C(binary_scalar_mul)(&j->GL[i], &j->GL[i], &j->GR[i], &t1, &t2);
+            FR(mul)(&t1, u, &j->Hf[i]); FR(mul)(&t2, ui, &j->Hf[n + i]);
+            C(binary_scalar_mul)(&j->HL[i], &j->HL[i], &j->HR[i], &t1, &t2);
+        } else {
+            C(binary_scalar_mul)(&j->GL[i], &j->GL[i], &j->GR[i], ui, u);
+            C(binary_scalar_mul)(&j->HL[i], &j->HL[i], &j->HR[i], u, ui);
+        }
+    }
 }
 
 /* Returns lg n.  L_out/R_out have room for lg n points. */
@@ -90,20 +120,8 @@ static int C(ipp_create)(orc_transcript* tr, const C(aff_t)* Q, const FR(t)* Gf,
         FR(t) u, ui;
         C(t_challenge_scalar)(tr, "u", &u);                                               /* :112 / :178 */
         FR(inv)(&ui, &u);                                                                 /* :113 / :179 */
-        for (size_t i = 0; i < n; i++) {                                                  /* :115-130 / :181-188 */
-            FR(t) t1, t2;
-            FR(mul)(&t1, &aL[i], &u); FR(mul)(&t2, &ui, &aR[i]); FR(add)(&aL[i], &t1, &t2);
-            FR(mul)(&t1, &bL[i], &ui); FR(mul)(&t2, &u, &bR[i]); FR(add)(&bL[i], &t1, &t2);
-            if (first) {
-                FR(mul)(&t1, &ui, &Gf[i]); FR(mul)(&t2, &u, &Gf[n + i]);
-                C(binary_scalar_mul)(&GL[i], &GL[i], &GR[i], &t1, &t2);
-                FR(mul)(&t1, &u, &Hf[i]); FR(mul)(&t2, &ui, &Hf[n + i]);
-                C(binary_scalar_mul)(&HL[i], &HL[i], &HR[i], &t1, &t2);
-            } else {
-                C(binary_scalar_mul)(&GL[i], &GL[i], &GR[i], &ui, &u);
-                C(binary_scalar_mul)(&HL[i], &HL[i], &HR[i], &u, &ui);
-            }
-        }
+        C(fold_job_t) fj = {aL, aR, bL, bR, GL, GR, HL, HR, Gf, Hf, n, first, u, ui};
+        orc_parallel_for(n, C(fold_range), &fj);                                          /* :115-130 / :181-188 */
         first = 0; rounds++;
     }
     *a_out = a[0]; *b_out = b[0];                                                         /* :196-201 */

@@ -468,3 +468,345 @@ class SplitMix64:
             v &= (1 << bits) - 1
             if v < curve.r:
                 return v
+
+
+# --------------------------------------------------------------------------- R1CS (src/r1cs)
+# Independent restatement of the R1CS layer for single- and two-commitment-phase-free systems, written from the
+# reference's sources (NOT from the product's orchestration in bulletproofs-amcl_amd/):
+#   ConstraintSystem bookkeeping     src/r1cs/prover.rs:84-127, 607-663 ; src/r1cs/verifier.rs (new/commit/allocate_multiplier)
+#   Prover::prove                    src/r1cs/prover.rs:322-593
+#   Verifier::verify                 src/r1cs/verifier.rs:267-457
+#   VecPoly3 / Poly6                 src/utils/vector_poly.rs:64-120
+#   bound_check_gadget               src/r1cs/gadgets/bound_check.rs:13-39
+#   positive_no_gadget               src/r1cs/gadgets/helper_constraints/positive_no.rs:8-40
+#   constrain_lc_with_scalar         src/r1cs/gadgets/helper_constraints/mod.rs:16-22
+# Variables are (kind, index) with kind 0/1/2 = MultiplierLeft/Right/Output, 3 = Committed, 4 = One; a linear combination is
+# a list of (variable, coefficient).  Randomness (blindings, s_L, s_R, the verifier's r) is passed in: the reference draws it
+# from its RNG (prover.rs:337-341,490-494; verifier.rs:392).
+
+V_LEFT, V_RIGHT, V_OUT, V_COMMITTED, V_ONE = 0, 1, 2, 3, 4
+ONE = (V_ONE, 0)
+
+
+def lc_scalar(curve, k):
+    """LinearCombination::from(FieldElement)"""
+    return [(ONE, k % curve.r)]
+
+
+def lc_neg(curve, lc):
+    return [(v, (-c) % curve.r) for v, c in lc]
+
+
+def lc_sub(curve, a, b):
+    return list(a) + lc_neg(curve, b)
+
+
+class R1CSProver:
+    """The prover side of the constraint system: src/r1cs/prover.rs:84-127 (new, commit), :607-663 (allocate_multiplier,
+    constrain).  Holds the witness (a_L, a_R, a_O, v, v_blinding) and the constraints."""
+
+    def __init__(self, curve, g, h, transcript):
+        self.curve, self.g, self.h, self.t = curve, g, h, transcript
+        transcript.append_message(b"dom-sep", b"r1cs v1")            # r1cs_domain_sep, prover.rs:85, transcript.rs:35-37
+        self.constraints, self.aL, self.aR, self.aO, self.v, self.v_blinding = [], [], [], [], [], []
+
+    def commit(self, v, v_blinding):                                   # prover.rs:118-127
+        c = self.curve
+        V = c.add(c.mul(v, self.g), c.mul(v_blinding, self.h))        # commit_to_field_element(g, h, v, r) = g v + h r
+        self.v.append(v % c.r)
+        self.v_blinding.append(v_blinding % c.r)
+        self.t.commit_point(c, b"V", V)
+        return V, (V_COMMITTED, len(self.v) - 1)
+
+    def allocate_multiplier(self, l, r):                               # prover.rs:649-657 (_allocate_vars)
+        i = len(self.aL)
+        self.aL.append(l % self.curve.r)
+        self.aR.append(r % self.curve.r)
+        self.aO.append(l * r % self.curve.r)
+        return (V_LEFT, i), (V_RIGHT, i), (V_OUT, i)
+
+    def multiply(self, left, right):                                   # prover.rs:607-626
+        l, r = self.eval(left), self.eval(right)
+        l_var, r_var, o_var = self.allocate_multiplier(l, r)
+        self.constrain(list(left) + [(l_var, self.curve.r - 1)])
+        self.constrain(list(right) + [(r_var, self.curve.r - 1)])
+        return l_var, r_var, o_var
+
+    def constrain(self, lc):                                           # prover.rs:659-663
+        self.constraints.append(list(lc))
+
+    def eval(self, lc):                                                # prover.rs:282-295
+        val = {V_LEFT: self.aL, V_RIGHT: self.aR, V_OUT: self.aO, V_COMMITTED: self.v}
+        return sum(c * (1 if v[0] == V_ONE else val[v[0]][v[1]]) for v, c in lc) % self.curve.r
+
+
+class R1CSVerifier:
+    """The verifier side: Verifier::new / commit / allocate_multiplier / constrain (src/r1cs/verifier.rs:60-147,459-520)."""
+
+    def __init__(self, curve, transcript):
+        self.curve, self.t = curve, transcript
+        transcript.append_message(b"dom-sep", b"r1cs v1")
+        self.constraints, self.V, self.num_vars = [], [], 0
+
+    def commit(self, V):
+        self.V.append(V)
+        self.t.commit_point(self.curve, b"V", V)
+        return (V_COMMITTED, len(self.V) - 1)
+
+    def allocate_multiplier(self, l=None, r=None):
+        i = self.num_vars
+        self.num_vars += 1
+        return (V_LEFT, i), (V_RIGHT, i), (V_OUT, i)
+
+    def multiply(self, left, right):                                   # verifier.rs (ConstraintSystem::multiply)
+        l_var, r_var, o_var = self.allocate_multiplier()
+        self.constrain(list(left) + [(l_var, self.curve.r - 1)])
+        self.constrain(list(right) + [(r_var, self.curve.r - 1)])
+        return l_var, r_var, o_var
+
+    def constrain(self, lc):
+        self.constraints.append(list(lc))
+
+
+def positive_no_gadget(cs, var, value, n):
+    """positive_no.rs:8-40.  value = the prover's assignment (None on the verifier side)."""
+    c = cs.curve
+    constraint_v = [(var, c.r - 1)]
+    exp_2 = 1
+    for i in range(n):
+        if value is None:
+            a, b, o = cs.allocate_multiplier()
+        elif (value >> i) & 1:
+            a, b, o = cs.allocate_multiplier(0, 1)
+        else:
+            a, b, o = cs.allocate_multiplier(1, 0)
+        cs.constrain([(o, 1)])                                         # a * b = 0
+        cs.constrain([(a, 1), (b, 1), (ONE, c.r - 1)])                 # a + (b - 1) = 0
+        constraint_v.append((b, exp_2))
+        exp_2 = (exp_2 + exp_2) % c.r
+    cs.constrain(constraint_v)                                         # -v + sum b_i 2^i = 0
+
+
+def bound_check_gadget(cs, v, a, b, vmax, vmin, n, a_val=None, b_val=None):
+    """bound_check.rs:13-39.  v, a, b: committed variables; a_val, b_val: the prover's assignments of a and b."""
+    c = cs.curve
+    cs.constrain(lc_sub(c, lc_sub(c, [(v, 1)], lc_scalar(c, vmin)), [(a, 1)]))      # v - min - a
+    cs.constrain(lc_sub(c, lc_sub(c, lc_scalar(c, vmax), [(v, 1)]), [(b, 1)]))      # max - v - b
+    cs.constrain(lc_sub(c, [(a, 1), (b, 1)], lc_scalar(c, vmax - vmin)))            # constrain_lc_with_scalar(a + b, max - min)
+    positive_no_gadget(cs, a, a_val, n)
+    positive_no_gadget(cs, b, b_val, n)
+
+
+def prove_bounded_num(prover, val, randomness, lower, upper, bits, blind_a, blind_b):
+    """bound_check.rs:41-91: commits v, a = v - lower, b = upper - v and adds the gadget.  Returns the commitments."""
+    a, b = val - lower, upper - val
+    Vv, var_v = prover.commit(val, randomness)
+    Va, var_a = prover.commit(a, blind_a)
+    Vb, var_b = prover.commit(b, blind_b)
+    bound_check_gadget(prover, var_v, var_a, var_b, upper, lower, bits, a, b)
+    return [Vv, Va, Vb]
+
+
+def verify_bounded_num(verifier, lower, upper, bits, commitments):
+    """bound_check.rs:93-129"""
+    vv, va, vb = (verifier.commit(C) for C in commitments)
+    bound_check_gadget(verifier, vv, va, vb, upper, lower, bits)
+
+
+def _flatten(curve, constraints, z, n, m):
+    """flattened_constraints: prover.rs:142-184 / verifier.rs:149-193 (wc only matters to the verifier)."""
+    r = curve.r
+    wL, wR, wO, wV, wc = [0] * n, [0] * n, [0] * n, [0] * m, 0
+    exp_z = z % r
+    for lc in constraints:
+        for (kind, i), coeff in lc:
+            t = exp_z * coeff % r
+            if kind == V_LEFT:
+                wL[i] = (wL[i] + t) % r
+            elif kind == V_RIGHT:
+                wR[i] = (wR[i] + t) % r
+            elif kind == V_OUT:
+                wO[i] = (wO[i] + t) % r
+            elif kind == V_COMMITTED:
+                wV[i] = (wV[i] - t) % r
+            else:
+                wc = (wc - t) % r
+        exp_z = exp_z * z % r
+    return wL, wR, wO, wV, wc
+
+
+def _next_pow2(n):
+    return 1 if n == 0 else 1 << (n - 1).bit_length()
+
+
+def r1cs_prove(prover, G, H, rand):
+    """Prover::prove, src/r1cs/prover.rs:322-593, for a system without deferred (second-phase) constraints.
+    rand: dict with i_blinding1, o_blinding1, s_blinding1, s_L1, s_R1 (lists of n), t_1_blinding, t_3_.., t_4_.., t_5_.., t_6_...
+    Returns a dict holding the fields of R1CSProof (src/r1cs/proof.rs:24-58)."""
+    c, t = prover.curve, prover.t
+    r = c.r
+    g, h = prover.g, prover.h
+    dot = lambda a, b: sum(x * y for x, y in zip(a, b)) % r
+    t.append_u64(b"m", len(prover.v))                                                          # :327
+    n1 = len(prover.aL)                                                                        # :330
+    assert len(G) >= n1                                                                        # :332
+    i_b1, o_b1, s_b1 = rand["i_blinding1"], rand["o_blinding1"], rand["s_blinding1"]           # :336-338
+    sL1, sR1 = list(rand["s_L1"]), list(rand["s_R1"])                                          # :340-341
+    assert len(sL1) == n1 and len(sR1) == n1
+    Gn, Hn = G[:n1], H[:n1]                                                                    # :343-344
+    A_I1 = c.add(c.add(c.msm(prover.aL, Gn), c.msm(prover.aR, Hn)), c.mul(i_b1, h))            # :347-355
+    A_O1 = c.add(c.msm(prover.aO, Gn), c.mul(o_b1, h))                                         # :358
+    S1 = c.add(c.add(c.msm(sL1, Gn), c.msm(sR1, Hn)), c.mul(s_b1, h))                          # :361-362
+    t.commit_point(c, b"A_I1", A_I1)
+    t.commit_point(c, b"A_O1", A_O1)
+    t.commit_point(c, b"S1", S1)                                                               # :364-366
+    t.append_message(b"dom-sep", b"r1cs-1phase")                                               # :369, :304-306 (no deferred constraints)
+    n = len(prover.aL)
+    n2 = n - n1                                                                                # 0
+    padded_n = _next_pow2(n)
+    pad = padded_n - n
+    assert len(G) >= padded_n                                                                  # :381
+    i_b2 = o_b2 = s_b2 = 0                                                                     # :398-402
+    A_I2 = A_O2 = S2 = None                                                                    # :429 identity
+    t.commit_point(c, b"A_I2", A_I2)
+    t.commit_point(c, b"A_O2", A_O2)
+    t.commit_point(c, b"S2", S2)                                                               # :432-434
+    y = t.challenge_scalar(c, b"y")
+    z = t.challenge_scalar(c, b"z")                                                            # :438-439
+    wL, wR, wO, wV, _ = _flatten(c, prover.constraints, z, n, len(prover.v))                   # :441
+    l1, l2, l3 = [0] * n, [0] * n, [0] * n
+    r0, r1, r3 = [0] * n, [0] * n, [0] * n
+    exp_y = 1
+    y_inv = pow(y, -1, r)
+    exp_y_inv = [pow(y_inv, i, r) for i in range(padded_n)]                                    # :463
+    for i in range(n):                                                                         # :469-486
+        l1[i] = (prover.aL[i] + exp_y_inv[i] * wR[i]) % r
+        l2[i] = prover.aO[i]
+        l3[i] = sL1[i]
+        r0[i] = (wO[i] - exp_y) % r
+        r1[i] = (exp_y * prover.aR[i] + wL[i]) % r
+        r3[i] = exp_y * sR1[i] % r
+        exp_y = exp_y * y % r
+    # VecPoly3::special_inner_product, vector_poly.rs:79-97 (lhs.0 = 0, rhs.2 = 0)
+    t1 = dot(l1, r0)
+    t2 = (dot(l1, r1) + dot(l2, r0)) % r
+    t3 = (dot(l2, r1) + dot(l3, r0)) % r
+    t4 = (dot(l1, r3) + dot(l3, r1)) % r
+    t5 = dot(l2, r3)
+    t6 = dot(l3, r3)
+    tb = {k: rand["t_%d_blinding" % k] for k in (1, 3, 4, 5, 6)}                               # :490-494
+    commit = lambda m_, r_: c.add(c.mul(m_, g), c.mul(r_, h))
+    T_1, T_3, T_4, T_5, T_6 = commit(t1, tb[1]), commit(t3, tb[3]), commit(t4, tb[4]), commit(t5, tb[5]), commit(t6, tb[6])   # :496-500
+    for label, P in ((b"T_1", T_1), (b"T_3", T_3), (b"T_4", T_4), (b"T_5", T_5), (b"T_6", T_6)):
+        t.commit_point(c, label, P)                                                            # :502-506
+    u = t.challenge_scalar(c, b"u")
+    x = t.challenge_scalar(c, b"x")                                                            # :508-509
+    t_2_blinding = dot(wV, prover.v_blinding)                                                  # :513
+    poly6 = lambda p1, p2, p3, p4, p5, p6: x * (p1 + x * (p2 + x * (p3 + x * (p4 + x * (p5 + x * p6))))) % r   # vector_poly.rs:116-119
+    t_x = poly6(t1, t2, t3, t4, t5, t6)                                                        # :524
+    t_x_blinding = poly6(tb[1], t_2_blinding, tb[3], tb[4], tb[5], tb[6])                      # :525
+    l_vec = [x * (l1[i] + x * (l2[i] + x * l3[i])) % r for i in range(n)] + [0] * pad          # :526-527 (l.0 = 0)
+    r_vec = [(r0[i] + x * (r1[i] + x * (x * r3[i]))) % r for i in range(n)]                    # :529 (r.2 = 0)
+    for _ in range(n, padded_n):                                                               # :532-535
+        r_vec.append((-exp_y) % r)
+        exp_y = exp_y * y % r
+    i_blinding = (i_b1 + u * i_b2) % r
+    o_blinding = (o_b1 + u * o_b2) % r
+    s_blinding = (s_b1 + u * s_b2) % r                                                         # :537-539
+    e_blinding = x * (i_blinding + x * (o_blinding + x * s_blinding)) % r                      # :541
+    t.commit_scalar(c, b"t_x", t_x)
+    t.commit_scalar(c, b"t_x_blinding", t_x_blinding)
+    t.commit_scalar(c, b"e_blinding", e_blinding)                                              # :543-546
+    w = t.challenge_scalar(c, b"w")
+    Q = c.mul(w, g)                                                                            # :549-550
+    G_factors = [1] * n1 + [u] * (n2 + pad)                                                    # :552-556
+    H_factors = [exp_y_inv[i] * G_factors[i] % r for i in range(padded_n)]                     # :557-563
+    Lv, Rv, a, b = ipp_create(c, t, Q, G_factors, H_factors, G[:padded_n], H[:padded_n], l_vec, r_vec)   # :565-574
+    return {"A_I1": A_I1, "A_O1": A_O1, "S1": S1, "A_I2": A_I2, "A_O2": A_O2, "S2": S2,
+            "T_1": T_1, "T_3": T_3, "T_4": T_4, "T_5": T_5, "T_6": T_6,
+            "t_x": t_x, "t_x_blinding": t_x_blinding, "e_blinding": e_blinding, "L": Lv, "R": Rv, "a": a, "b": b}
+
+
+def r1cs_verifier_msm(verifier, proof, g, h, G, H, rnd):
+    """Verifier::verify, src/r1cs/verifier.rs:267-451 up to the single MSM: returns (scalars, points) of
+    `inner_product_var_time_with_ref_vecs(arg2, arg1)`, or None on the error exits.  rnd = the verifier's random r (:392)."""
+    c, t = verifier.curve, verifier.t
+    r = c.r
+    t.append_u64(b"m", len(verifier.V))                                                        # :279
+    n1 = verifier.num_vars
+    t.commit_point(c, b"A_I1", proof["A_I1"])
+    t.commit_point(c, b"A_O1", proof["A_O1"])
+    t.commit_point(c, b"S1", proof["S1"])                                                      # :282-284
+    t.append_message(b"dom-sep", b"r1cs-1phase")                                               # :287 (no deferred constraints)
+    n = verifier.num_vars
+    n2 = n - n1
+    padded_n = _next_pow2(n)
+    pad = padded_n - n
+    if len(G) < padded_n:
+        return None                                                                            # :297-299
+    t.commit_point(c, b"A_I2", proof["A_I2"])
+    t.commit_point(c, b"A_O2", proof["A_O2"])
+    t.commit_point(c, b"S2", proof["S2"])                                                      # :301-303
+    y = t.challenge_scalar(c, b"y")
+    z = t.challenge_scalar(c, b"z")
+    for label in ("T_1", "T_3", "T_4", "T_5", "T_6"):
+        t.commit_point(c, label.encode(), proof[label])                                        # :308-312
+    u = t.challenge_scalar(c, b"u")
+    x = t.challenge_scalar(c, b"x")
+    t.commit_scalar(c, b"t_x", proof["t_x"])
+    t.commit_scalar(c, b"t_x_blinding", proof["t_x_blinding"])
+    t.commit_scalar(c, b"e_blinding", proof["e_blinding"])                                     # :317-321
+    w = t.challenge_scalar(c, b"w")
+    wL, wR, wO, wV, wc = _flatten(c, verifier.constraints, z, n, len(verifier.V))              # :325
+    a, b = proof["a"], proof["b"]
+    y_inv = pow(y, -1, r)
+    y_inv_vec = [pow(y_inv, i, r) for i in range(padded_n)]                                    # :342
+    y_inv_wR = [wR[i] * y_inv_vec[i] % r for i in range(n)] + [0] * pad                        # :343-348
+    delta = sum(y_inv_wR[i] * wL[i] for i in range(n)) % r                                     # :350-352
+    vs = ipp_verification_scalars(c, proof["L"], proof["R"], padded_n, t)                      # :354-360
+    if vs is None:
+        return None
+    u_sq, u_inv_sq, s = vs
+    u_or_1 = [1] * n1 + [u] * (n2 + pad)                                                       # :362-365
+    g_scalars = [u_or_1[i] * (x * y_inv_wR[i] - a * s[i]) % r for i in range(padded_n)]        # :368-373
+    wLp, wOp = wL + [0] * pad, wO + [0] * pad
+    s_rev = s[::-1]
+    h_scalars = [u_or_1[i] * (y_inv_vec[i] * (x * wLp[i] + wOp[i] - b * s_rev[i]) - 1) % r for i in range(padded_n)]   # :375-390
+    x_sqr = x * x % r
+    x_cube = x * x_sqr % r
+    r_x_sqr = rnd * x_sqr % r
+    rx, rx3 = rnd * x % r, rnd * x_cube % r
+    rx4 = rx3 * x % r
+    rx5 = rx4 * x % r
+    rx6 = rx5 * x % r                                                                          # :398-408
+    arg1 = [x, x_sqr, x_cube, u * x % r, u * x_sqr % r, u * x_cube % r]                        # :412-415
+    arg1 += [wv * r_x_sqr % r for wv in wV]                                                    # :416-418
+    arg1 += [rx, rx3, rx4, rx5, rx6]                                                           # :419
+    arg1.append((w * (proof["t_x"] - a * b) + rnd * (x_sqr * (wc + delta) - proof["t_x"])) % r)   # :421-422
+    arg1.append((-(proof["e_blinding"] + rnd * proof["t_x_blinding"])) % r)                    # :424-425
+    arg1 += g_scalars + h_scalars + [v % r for v in u_sq] + [v % r for v in u_inv_sq]          # :426-429
+    arg2 = [proof["A_I1"], proof["A_O1"], proof["S1"], proof["A_I2"], proof["A_O2"], proof["S2"]]
+    arg2 += list(verifier.V) + [proof[k] for k in ("T_1", "T_3", "T_4", "T_5", "T_6")] + [g, h]
+    arg2 += list(G[:padded_n]) + list(H[:padded_n]) + list(proof["L"]) + list(proof["R"])     # :431-446
+    return arg1, arg2
+
+
+def r1cs_verify(verifier, proof, g, h, G, H, rnd):
+    """Verifier::verify (src/r1cs/verifier.rs:267-457): True iff the MSM is the identity (:451-454)."""
+    m = r1cs_verifier_msm(verifier, proof, g, h, G, H, rnd)
+    if m is None:
+        return False
+    return verifier.curve.msm(m[0], m[1]) is None
+
+
+def r1cs_proof_to_le(curve, proof):
+    """The proof in the C ABI's layout (include/bpmsm.h, bp_r1cs_proof_bytes): 11 points | t_x t_x_blinding e_blinding | L R | a b."""
+    out = b"".join(curve.g1_to_le(proof[k]) for k in ("A_I1", "A_O1", "S1", "A_I2", "A_O2", "S2", "T_1", "T_3", "T_4", "T_5", "T_6"))
+    out += b"".join(curve.fr_to_le(proof[k]) for k in ("t_x", "t_x_blinding", "e_blinding"))
+    out += b"".join(curve.g1_to_le(P) for P in proof["L"]) + b"".join(curve.g1_to_le(P) for P in proof["R"])
+    return out + curve.fr_to_le(proof["a"]) + curve.fr_to_le(proof["b"])
+
+
+def constraints_to_terms(constraints):
+    """Flat (constraint, kind, index, coeff) tuples -- the term lists the C ABI and the C oracle take."""
+    return [(q, v[0], v[1], c) for q, lc in enumerate(constraints) for v, c in lc]

@@ -30,7 +30,8 @@ def lib():
         L.orc_transcript_size.restype = ctypes.c_size_t
         for name in ("orc_msm", "orc_g1_fixed_base_batch", "orc_fr_inner", "orc_random_scalars", "orc_ipp_create",
                      "orc_ipp_verify", "orc_ipp_verification_scalars", "orc_transcript_new",
-                     "orc_transcript_append_message", "orc_transcript_challenge_bytes"):
+                     "orc_transcript_append_message", "orc_transcript_challenge_bytes", "orc_r1cs_prove", "orc_r1cs_verify",
+                     "orc_r1cs_flattened_constraints", "orc_set_threads"):
             getattr(L, name).argtypes = None
         _lib = L
     return _lib
@@ -151,6 +152,9 @@ class Transcript:
         assert lib().orc_transcript_challenge_scalar(curve, self.buf, label, out) == 0
         return out.raw
 
+    def commit_scalar(self, curve, label, x):
+        assert lib().orc_transcript_commit_scalar(curve, self.buf, label, bytes(x)) == 0
+
 
 def ipp_create(curve, tr, Q, Gf, Hf, G, H, a, b, n):
     lg = max(0, n.bit_length() - 1)
@@ -197,3 +201,60 @@ def group_order(curve):
     """r of the curve (public constant)."""
     return (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001 if curve == 0
             else 0x2523648240000001BA344D8000000007FF9F800000000010A10000000000000D)
+
+
+def set_threads(k):
+    """Worker threads inside orc_ipp_* / orc_r1cs_* (MSMs and the fold loop); results do not depend on k."""
+    lib().orc_set_threads(ctypes.c_int(k))
+
+
+class R1CSTerms:
+    """A constraint system as the flat term arrays orc_r1cs_* take: terms = [(constraint, kind, index, coeff int or 32-byte LE)]."""
+
+    def __init__(self, terms, n_constraints, n, m):
+        import numpy as np
+        k = len(terms)
+        self.k, self.nq, self.n, self.m = k, n_constraints, n, m
+        self.con = np.ascontiguousarray([t[0] for t in terms], dtype=np.uint32)
+        self.kind = np.ascontiguousarray([t[1] for t in terms], dtype=np.uint8)
+        self.idx = np.ascontiguousarray([t[2] for t in terms], dtype=np.uint32)
+        self.coeff = b"".join(t[3] if isinstance(t[3], (bytes, bytearray)) else int(t[3]).to_bytes(32, "little") for t in terms)
+
+    def args(self):
+        return (ctypes.c_size_t(self.k), self.con.ctypes.data_as(ctypes.c_void_p), self.kind.ctypes.data_as(ctypes.c_void_p),
+                self.idx.ctypes.data_as(ctypes.c_void_p), self.coeff, ctypes.c_size_t(self.nq), ctypes.c_size_t(self.n), ctypes.c_size_t(self.m))
+
+
+def r1cs_start_transcript(curve, label, V_list):
+    """What Prover::new / Verifier::new and commit put on the transcript (src/r1cs/prover.rs:84-127)."""
+    t = Transcript(label)
+    t.append_message(b"dom-sep", b"r1cs v1")
+    for V in V_list:
+        t.commit_point(curve, b"V", V)
+    return t
+
+
+def r1cs_proof_bytes(curve, n):
+    lg = max(0, (n - 1).bit_length())
+    return 11 * pt_bytes(curve) + 3 * 32 + 2 * lg * pt_bytes(curve) + 2 * 32
+
+
+def r1cs_prove(curve, tr, cs, g, h, G, H, ngens, aL, aR, aO, v_blinding, sL, sR, blindings):
+    """Prover::prove (src/r1cs/prover.rs:322-593) in the C oracle -> (rc, proof bytes)."""
+    out = _buf(r1cs_proof_bytes(curve, cs.n))
+    rc = lib().orc_r1cs_prove(ctypes.c_int(curve), tr.buf, *cs.args(), bytes(g), bytes(h), bytes(G), bytes(H), ctypes.c_size_t(ngens),
+                              bytes(aL), bytes(aR), bytes(aO), bytes(v_blinding), bytes(sL), bytes(sR), bytes(blindings), out)
+    return rc, out.raw
+
+
+def r1cs_verify(curve, tr, cs, V, proof, g, h, G, H, ngens, rnd):
+    """Verifier::verify (src/r1cs/verifier.rs:267-457) in the C oracle -> 0 accepted / 3 rejected."""
+    return lib().orc_r1cs_verify(ctypes.c_int(curve), tr.buf, *cs.args(), bytes(V), bytes(proof), ctypes.c_size_t(len(proof)), bytes(g), bytes(h),
+                                 bytes(G), bytes(H), ctypes.c_size_t(ngens), bytes(rnd))
+
+
+def r1cs_flattened_constraints(curve, cs, z):
+    n, m = cs.n, cs.m
+    wL, wR, wO, wV, wc = _buf(max(1, n) * 32), _buf(max(1, n) * 32), _buf(max(1, n) * 32), _buf(max(1, m) * 32), _buf(32)
+    assert lib().orc_r1cs_flattened_constraints(ctypes.c_int(curve), *cs.args(), bytes(z), wL, wR, wO, wV, wc) == 0
+    return wL.raw[: n * 32], wR.raw[: n * 32], wO.raw[: n * 32], wV.raw[: m * 32], wc.raw

@@ -183,3 +183,76 @@ def test_hash_to_g1_golden(golden, name):
     p = bytes.fromhex(pts[0])
     rm1 = O.g1_mul(cid, (r - 1).to_bytes(32, "little"), p)
     assert O.g1_add(cid, rm1, p) == bytes(len(p))
+
+
+def r1cs_case_inputs(c):
+    """Fixture case (tests/golden/r1cs.json) -> the byte arguments of O.r1cs_prove / O.r1cs_verify and of the C ABI."""
+    cat = lambda key: b"".join(hx(x) for x in c[key])
+    terms = [(q, k, i, hx(cf)) for q, k, i, cf in c["terms"]]
+    return {"terms": terms, "label": hx(c["label"]), "g": hx(c["g"]), "h": hx(c["h"]), "G": cat("G"), "H": cat("H"), "V": [hx(v) for v in c["V"]],
+            "aL": cat("a_L"), "aR": cat("a_R"), "aO": cat("a_O"), "vb": cat("v_blinding"), "sL": cat("s_L"), "sR": cat("s_R"),
+            "blind": cat("blindings"), "proof": hx(c["proof"]), "r": hx(c["verifier_r"])}
+
+
+@pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("threads", [1, 3])
+def test_r1cs_golden(golden, name, threads):
+    """Prover::prove / Verifier::verify in the C oracle (oracle/orc_r1cs_tmpl.h) against whole proofs made by the Python-int
+    restatement (oracle/pyref.py r1cs_prove): same bytes, accepted, and rejected after any single change."""
+    cid = O.CURVE_IDS[name]
+    O.set_threads(threads)
+    try:
+        for c in golden("r1cs")[name]:
+            a = r1cs_case_inputs(c)
+            cs = O.R1CSTerms(a["terms"], c["n_constraints"], c["n"], c["m"])
+            ng = c["n_generators"]
+            rc, proof = O.r1cs_prove(cid, O.r1cs_start_transcript(cid, a["label"], a["V"]), cs, a["g"], a["h"], a["G"], a["H"], ng,
+                                     a["aL"], a["aR"], a["aO"], a["vb"], a["sL"], a["sR"], a["blind"])
+            assert rc == 0 and proof == a["proof"], c["name"]
+            Vb = b"".join(a["V"])
+            verify = lambda pf, V=Vb, r=a["r"]: O.r1cs_verify(cid, O.r1cs_start_transcript(cid, a["label"], a["V"]), cs, V, pf, a["g"], a["h"],
+                                                               a["G"], a["H"], ng, r)
+            assert verify(proof) == 0, c["name"]
+            assert verify(proof, r=(12345).to_bytes(32, "little")) == 0          # any weight accepts an honest proof
+            pb = O.pt_bytes(cid)
+            for off in (11 * pb, 11 * pb + 32, 11 * pb + 64, len(proof) - 1, len(proof) - 33):     # t_x, t_x_blinding, e_blinding, b, a
+                bad = bytearray(proof)
+                bad[off] ^= 1
+                assert verify(bytes(bad)) == 3, (c["name"], off)
+            swapped = proof[pb:2 * pb] + proof[:pb] + proof[2 * pb:]                 # A_I1 <-> A_O1
+            assert verify(swapped) == 3
+            assert verify(proof[:-1]) == 3                                           # wrong length
+            if c["m"]:
+                V2 = Vb[pb:2 * pb] + Vb[:pb] + Vb[2 * pb:] if c["m"] > 1 else O.generator(cid)
+                if V2 != Vb:
+                    assert O.r1cs_verify(cid, O.r1cs_start_transcript(cid, a["label"], a["V"]), cs, V2, proof, a["g"], a["h"], a["G"], a["H"],
+                                         ng, a["r"]) == 3
+            assert O.r1cs_prove(cid, O.r1cs_start_transcript(cid, a["label"], a["V"]), cs, a["g"], a["h"], a["G"], a["H"], max(1, c["n"]) - 1,
+                                a["aL"], a["aR"], a["aO"], a["vb"], a["sL"], a["sR"], a["blind"])[0] == (1 if c["n"] > 0 else 0)   # InvalidGeneratorsLength
+    finally:
+        O.set_threads(1)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_r1cs_flatten_vs_pyref(name):
+    """flattened_constraints (src/r1cs/verifier.rs:149-193): C oracle against the Python-int restatement on a random system."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    cv = R.CURVES[name]
+    cid = O.CURVE_IDS[name]
+    rng = R.SplitMix64(77 + cid)
+    n, m, nq = 13, 4, 29
+    cons = []
+    for q in range(nq):
+        lc = []
+        for _ in range(1 + rng.next() % 5):
+            kind = rng.next() % 5
+            lc.append(((kind, rng.next() % (m if kind == 3 else n)), rng.scalar(cv)))
+        cons.append(lc)
+    z = rng.scalar(cv)
+    want = R._flatten(cv, cons, z, n, m)
+    cs = O.R1CSTerms(R.constraints_to_terms(cons), nq, n, m)
+    got = O.r1cs_flattened_constraints(cid, cs, z.to_bytes(32, "little"))
+    ints = lambda b: [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+    assert [ints(g) for g in got[:4]] == [list(w) for w in want[:4]] and int.from_bytes(got[4], "little") == want[4]
