@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- BLS12-381 G1 multi-scalar-multiplication throughput on MI355X (BASELINE.json metric).
 
-A "step" is one MSM  sum_i s_i P_i  over synthetic inputs already resident in HBM: n_per_gpu = 2^20 random points
-(k_i * G, generated on the device) and 2^20 uniformly random scalars per GPU.  With N > 1 ranks (one process per
-GPU, launched by torch.distributed.run) the index range is sharded: every rank runs the bucket pipeline on its own
-2^20-point slice, the per-window bucket sums (16 records x 192 B per rank) are all-gathered over RCCL, and the MSM
-over all N * 2^20 points is finished on every rank ("scaling": "weak").  Output: ONE JSON line on rank 0.
+A "step" is one MSM  sum_i s_i P_i  over synthetic inputs already resident in HBM: random points (k_i * G, generated on
+the device) and uniformly random scalars.  With N > 1 ranks (one process per GPU) the index range is sharded: every rank
+runs the bucket pipeline on its own slice, the per-window bucket sums (16 records x 192 B + a geometry header per rank) are
+all-gathered over RCCL, and the MSM over all points is finished on every rank.
+  default ("scaling": "weak")   2^lg-n points PER GPU (2^20: the headline configuration, BASELINE config 2)
+  --strong ("scaling": "strong") 2^lg-n points IN TOTAL, split by index range (default 2^22: BASELINE config 4, 2^19 per GPU at 8)
+`python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (torch.distributed.run, before anything
+touches a GPU) and relays rank 0's line; under an external torchrun it joins the group it is given.  Output: ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--lg-n 20] [--curve bls12_381] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--strong] [--lg-n L] [--curve bls12_381] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -24,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ACC_KERNEL_PREFIX = "bp::k_accumulate<bp::Bls381"   # dominant kernel as rocprofv3 names it
 
 
 def random_scalars(r, bits, n, seed):
@@ -44,29 +48,70 @@ def random_scalars(r, bits, n, seed):
     return out.tobytes()
 
 
+def self_launch(args):
+    """--gpus N > 1 without a process group in the environment: start N ranks (one per GPU) and relay rank 0's JSON line.
+    Nothing in this process has touched the GPU (counting devices does not initialise it)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.rehearse_one_device:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return p.returncode if p.returncode else (0 if lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lg-n", type=int, default=20, help="log2 of the points per GPU")
+    ap.add_argument("--lg-n", type=int, default=None, help="log2 of the points per GPU (weak, default 20) or in total (--strong, default 22)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the total size is fixed and split over the ranks (BASELINE config 4)")
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="also time the same MSMs with two in flight (extra field; off by default so that rocprofv3 averages of the default "
                          "command are not mixed with concurrently running kernels)")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="N ranks that all use GPU 0 and exchange their records over gloo: rehearses the N > 1 code path (self-launch, "
+                         "sharding, gather, finish) on a one-GPU box; the line is marked \"rehearsal\": true and is not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.lg_n is None:
+        args.lg_n = 22 if args.strong else 20
+    in_group = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_group:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_group else 1
+    rank = int(os.environ.get("RANK", "0")) if in_group else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_group else 0
+    if args.rehearse_one_device:
+        local_rank = 0
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # Launched by torch.distributed.run (even with one rank): go through RCCL so that the sharded path is the one
     # that runs.  A plain `python bench.py` is the single-GPU path with no process group.
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    use_dist = in_group
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -76,7 +121,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if args.rehearse_one_device:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
             torch.cuda.set_device(local_rank)
             dist.barrier()
             torch.cuda.synchronize()
@@ -84,8 +132,6 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -95,18 +141,30 @@ def main():
     ctx = bp.Context(curve, local_rank)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     info = bp.curve_info(curve)
-    n = 1 << args.lg_n
+    if args.strong:
+        n_total = 1 << args.lg_n
+        lo, hi = sharding.shard_range(n_total, world, rank)
+        n = hi - lo
+        n_set = sharding.largest_shard(n_total, world)
+        if world > 1 and n_total % world:
+            ctx.set_window_bits(sharding.common_window_bits(bp, curve, n_total, world))    # unequal shards: one width for all ranks
+    else:
+        n = 1 << args.lg_n
+        n_total = world * n
+        n_set = n
+    shard_sizes = [n] if not args.strong else [b - a for a, b in (sharding.shard_range(n_total, world, r) for r in range(world))]
     unit_bytes = 2 * info.fp_bytes + 32          # algorithmic bytes per scalar-mul: affine point + scalar
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------------------
-    k_bytes = random_scalars(ctx.r, info.fr_bits, n, 0xB0117E7 + 2 * rank)
-    s_bytes = random_scalars(ctx.r, info.fr_bits, n, 0xB0117E7 + 2 * rank + 1)
+    seed_of = lambda rk: 0xB0117E7 + 2 * rk
+    k_bytes = random_scalars(ctx.r, info.fr_bits, n, seed_of(rank))
+    s_bytes = random_scalars(ctx.r, info.fr_bits, n, seed_of(rank) + 1)
     kv = bp.FieldElementVector.from_bytes(ctx, k_bytes, n)
     pts = bp.G1Vector.fixed_base(ctx, kv)             # P_i = k_i * G, generated on the device
     sv = bp.FieldElementVector.from_bytes(ctx, s_bytes, n)
     ctx.synchronize()
 
-    W = bp.msm_window_records(ctx, n)
+    W = bp.msm_window_records(ctx, n_set)             # window records + geometry header per rank
     rb = bp.msm_record_bytes(curve)
     mine = torch.zeros(W * rb, dtype=torch.uint8, device=dev)
 
@@ -116,7 +174,7 @@ def main():
         bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
         allrec = sharding.all_gather_records(mine, world)          # RCCL all_gather_into_tensor
         torch.cuda.current_stream(dev).synchronize()               # the gather must be complete before the D2H of finish
-        return bp.msm_finish(ctx, allrec.data_ptr(), world, n)
+        return bp.msm_finish(ctx, allrec.data_ptr(), world, n_set)
 
     def fence():
         if use_dist:
@@ -132,12 +190,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- extra (not `value`): the same K MSMs with two in flight (two contexts / HIP streams, one host thread).
-    # The bucket reduce is latency-bound (one wave per SIMD), so a second MSM in flight fills the idle lanes.
     overlapped = None
     if not use_dist and args.overlap:
         ctxs2 = [bp.Context(curve, local_rank) for _ in range(2)]
@@ -177,22 +234,23 @@ def main():
     if acc_ms:
         names = ["device_total", "digits_count", "scan", "scatter", "tasks", "accumulate", "reduce"]
         stages = {k: round(float(v), 4) for k, v in zip(names, tm)}
+    n_windows = len(bp.msm_geometry(curve, n_set, 0)[1])
 
     out = None
     if rank == 0:
-        total_units = world * n
-        value = total_units * args.steps / elapsed
+        value = n_total * args.steps / elapsed
         roofline = None
+        # HBM bytes per k_accumulate launch: from a committed rocprofv3 --pmc run of THIS command whose kernel names match the
+        # library being benchmarked (profiles/README lists how it was taken); raw FETCH_SIZE + WRITE_SIZE (the guide's x2 read
+        # correction is calibrated for wide streaming reads, not for 96-byte row gathers, so it is not applied).
         traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc_hbm.json")
-        if args.curve == "bls12_381" and args.lg_n == 20 and os.path.exists(pmc):
-            # HBM bytes per k_accumulate launch from the committed rocprofv3 --pmc passes of this same command
-            # (FETCH_SIZE / WRITE_SIZE in KiB; read side doubled per MI355X_MICROARCH.md, uncalibrated for gathers)
-            ks = json.load(open(pmc))["kernels"]
-            k = next((v for name, v in ks.items() if name.startswith("bp::k_accumulate<bp::Bls381")), {})
+        pmc = os.path.join(ROOT, "profiles", "r02_bench_n1_pmc_hbm.json")
+        if args.curve == "bls12_381" and args.lg_n == 20 and not args.strong and os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            k = next((v for name, v in pj.get("kernels", {}).items() if name.startswith(ACC_KERNEL_PREFIX)), {})
             if "FETCH_SIZE_KiB_avg" in k and "WRITE_SIZE_KiB_avg" in k:
-                traffic = int((2 * k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
-                traffic_note = "profiles/r01_bench_n1_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
+                traffic = int((k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
+                traffic_note = "stored profile profiles/r02_bench_n1_pmc_hbm.json (%s): raw FETCH_SIZE + WRITE_SIZE per launch" % pj.get("taken", "?")
         if acc_ms:
             avg = float(np.mean(acc_ms)) * 1e-3
             achieved = n * unit_bytes / avg / 1e9
@@ -200,44 +258,55 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_note,
                         "kernel_ms": round(avg * 1e3, 4), "algorithmic_bytes_per_launch": n * unit_bytes,
                         "pipeline_GBs": round(n * unit_bytes / (float(np.mean(dev_ms)) * 1e-3) / 1e9, 2)}
-            # The kernel is ALU-bound (VALU ~91 % busy, profiles/r01_bench_n1_pmc_sq.json), so the HBM fraction above says
-            # little about it; beside it, the field-multiplication rate against the microbenchmarked ceiling of the same
-            # multiplier (microbench/fpmul_rate.hip, formulation C at 8 waves/SIMD).  One mixed addition = 8M + 2S.
+            # The kernel is integer-ALU bound, so the HBM fraction says little about it.  Beside it: the rate of mixed additions
+            # against (a) the instruction-ISSUE ceiling -- a mixed addition is 8 products + 2 squares = 8 x 351 + 2 x 273
+            # multiply-class instructions (v_mad_u64_u32 / v_mul_lo) at the measured 4.5 cycles per wave64 instruction per SIMD,
+            # 1024 SIMDs at 2.4 GHz, nothing else counted -- and (b) this library's own multiplier loop (microbench/fpmul_rate.hip).
             if args.curve == "bls12_381":
-                fpmul = n * int(W) * 10 / avg
-                roofline["alu"] = {"achieved": round(fpmul, 0), "peak": 6.6e10, "unit": "381-bit Fp-mul/s", "frac": round(fpmul / 6.6e10, 4),
-                                   "how": "n * windows mixed additions * 10 products each / kernel time; peak = microbench/fpmul_rate.hip"}
+                adds = n * n_windows / avg
+                issue_peak = 1024 * 64 * 2.4e9 / ((8 * 351 + 2 * 273) * 4.5)
+                roofline["alu"] = {"achieved": round(adds, 0), "unit": "mixed additions/s", "peak": round(issue_peak, 0), "frac": round(adds / issue_peak, 4),
+                                   "how": "n * windows additions / kernel time; peak = issue limit of the multiply instructions alone (8*351 + 2*273 per addition, "
+                                          "4.5 cyc per wave64 instruction, 1024 SIMDs, 2.4 GHz)",
+                                   "vs_own_multiplier_microbench": round(adds * 10 / 6.6e10, 4)}
         out = {
-            "metric": "BLS12-381 G1 scalar-muls/s at n=2^20 MSM" if (args.curve == "bls12_381" and args.lg_n == 20) else
-                      "%s G1 scalar-muls/s at n=2^%d MSM" % (args.curve, args.lg_n),
+            "metric": "BLS12-381 G1 scalar-muls/s at n=2^20 MSM" if (args.curve == "bls12_381" and args.lg_n == 20 and not args.strong) else
+                      "%s G1 scalar-muls/s at n=2^%d MSM%s" % (args.curve, args.lg_n, " (total, strong scaling)" if args.strong else ""),
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "2^%d-point %s G1 Pippenger MSM per GPU, uniform random scalars, points k_i*G, inputs resident in HBM"
-                                   % (args.lg_n, args.curve),
-                       "curve": args.curve, "n_per_gpu": n, "n_total": total_units, "windows": int(W),
-                       "sharding": "index range per rank, all_gather of %d window records/rank over RCCL" % W if use_dist else "single GPU"},
+            "config": {"workload": ("2^%d-point %s G1 Pippenger MSM in total, index range split over the GPUs" if args.strong else
+                                    "2^%d-point %s G1 Pippenger MSM per GPU") % (args.lg_n, args.curve) +
+                                   ", uniform random scalars, points k_i*G, inputs resident in HBM",
+                       "curve": args.curve, "n_per_gpu": max(shard_sizes), "n_total": n_total, "windows": n_windows,
+                       "sharding": "index range per rank, all_gather of %d records/rank (windows + geometry header) over RCCL" % W if use_dist else "single GPU"},
             "stages_ms": stages,
             "roofline": roofline,
             "overlapped_2_streams": overlapped,
         }
+        if args.rehearse_one_device:
+            out["rehearsal"] = True
 
     # ---- correctness of the timed result: MSM(s, k.G) == (<s,k> mod r).G  (oracle = checker only) ------------------
+    failed = False
     if not args.no_verify:
         import _oracle as O
         if rank == 0:
             acc = 0
             for rk in range(world):
-                kb = k_bytes if rk == 0 else random_scalars(ctx.r, info.fr_bits, n, 0xB0117E7 + 2 * rk)
-                sb = s_bytes if rk == 0 else random_scalars(ctx.r, info.fr_bits, n, 0xB0117E7 + 2 * rk + 1)
-                acc = (acc + int.from_bytes(O.fr_inner(curve, kb, sb, n), "little")) % ctx.r
+                nk = shard_sizes[rk] if args.strong else n
+                kb = k_bytes if rk == 0 else random_scalars(ctx.r, info.fr_bits, nk, seed_of(rk))
+                sb = s_bytes if rk == 0 else random_scalars(ctx.r, info.fr_bits, nk, seed_of(rk) + 1)
+                acc = (acc + int.from_bytes(O.fr_inner(curve, kb, sb, nk), "little")) % ctx.r
             want = O.g1_mul(curve, acc.to_bytes(32, "little"), O.generator(curve))
             out["verified"] = bool(result == want)
             if not out["verified"]:
-                print("ERROR: MSM result does not match the oracle", file=sys.stderr)
+                failed = True
+                print("ERROR: MSM result does not match the oracle -- no value is reported", file=sys.stderr)
+                out["value"] = None                      # a wrong result is not a measurement
 
     # ---- CPU baseline on this box's host cores (rank 0, N = 1 only; bounded sample) --------------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not failed:
         import _oracle as O
         cores = os.cpu_count() or 1
         ns = min(n, 1 << 17)                      # Strauss/wNAF-5, one thread: the reference's algorithm class
@@ -246,7 +315,7 @@ def main():
         out["cpu_baseline"] = {"value": ns / sec1, "unit": "scalar-muls/s", "cores": 1, "kind": "port",
                                "sample": "first 2^%d terms of the same inputs, single-thread Strauss/wNAF-5 restatement of amcl_wrapper's "
                                          "multi_scalar_mul_var_time (oracle/orc_curve_tmpl.h), %.2f s" % (ns.bit_length() - 1, sec1)}
-        nb = n
+        nb = min(n, 1 << 20)
         host_pts = pts.to_bytes(0, nb)
         r2, sec2 = O.msm_timed(curve, host_pts, s_bytes[: nb * 32], nb, O.PIPPENGER, cores)
         out["cpu_baseline_best"] = {"value": nb / sec2, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
@@ -261,6 +330,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -100,6 +100,14 @@ SYMBOLS = {
     "bp_msm_record_bytes": (_SZ, [_I]),
     "bp_msm_g1_windows": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _P]),
     "bp_msm_g1_finish": (_I, [_P, _P, _SZ, _SZ, _U8P]),
+    "bp_msm_g1_finish_host": (_I, [_I, _U8P, _SZ, _SZ, _I, _U8P]),
+    "bp_msm_geometry": (_I, [_I, _SZ, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _P, _P, _U8P]),
+    "bp_msm_record_from_affine": (_I, [_I, _U8P, _P]),
+    "bp_msm_record_header": (_I, [_I, _SZ, _I, _P]),
+    "bp_msm_g1_multi": (_I, [_PP, _PP, _PP, _SZ, _U8P]),
+    "bp_ctx_trim": (_I, [_P]),
+    "bp_fr_random": (_I, [_I, _U8P, _SZ]),
+    "bp_fr_is_canonical_nonzero": (_I, [_I, _U8P]),
     "bp_msm_last_timing": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "bp_fr_inner_product": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _U8P]),
     "bp_fr_hadamard": (_I, [_P, _P, _P, _PP]),
@@ -212,6 +220,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().bp_ctx_synchronize(self.h), "bp_ctx_synchronize")
+
+    def trim(self):
+        """give the cached blocks of the context's memory pool back to the driver"""
+        _check(lib().bp_ctx_trim(self.h), "bp_ctx_trim")
 
     def set_device_tail(self, on):
         _check(lib().bp_ctx_set_device_tail(self.h, 1 if on else 0), "bp_ctx_set_device_tail")
@@ -414,7 +426,53 @@ def msm_finish(ctx, device_records_ptr, sets, n_per_set):
 
 
 def msm_window_records(ctx, n):
+    """records per block: W window records + the geometry header"""
     return lib().bp_msm_window_records(ctx.h, n)
+
+
+def msm_finish_host(curve, host_records, sets, n_per_set, window_bits=0):
+    """Stage 2 of the sharded MSM on host memory (no GPU): validates the headers, folds `sets` record blocks."""
+    out = ctypes.create_string_buffer(2 * (48 if curve == BLS12_381 else 32))
+    _check(lib().bp_msm_g1_finish_host(curve, bytes(host_records), sets, n_per_set, window_bits, out), "bp_msm_g1_finish_host")
+    return out.raw
+
+
+def msm_geometry(curve, n, window_bits=0):
+    """-> (c, [cw_w], [off_w], bias int): the window table an MSM of n terms uses (bp_msm_geometry)."""
+    c, W = ctypes.c_int(), ctypes.c_int()
+    cw, off, bias = (ctypes.c_uint8 * 256)(), (ctypes.c_uint16 * 256)(), ctypes.create_string_buffer(32)
+    _check(lib().bp_msm_geometry(curve, n, window_bits, ctypes.byref(c), ctypes.byref(W), ctypes.cast(cw, ctypes.c_void_p),
+                                 ctypes.cast(off, ctypes.c_void_p), bias), "bp_msm_geometry")
+    return c.value, list(cw[:W.value]), list(off[:W.value]), int.from_bytes(bias.raw, "little")
+
+
+def msm_record_from_affine(curve, point_le):
+    out = ctypes.create_string_buffer(lib().bp_msm_record_bytes(curve))
+    _check(lib().bp_msm_record_from_affine(curve, bytes(point_le), ctypes.cast(out, ctypes.c_void_p)), "bp_msm_record_from_affine")
+    return out.raw
+
+
+def msm_record_header(curve, n, window_bits=0):
+    out = ctypes.create_string_buffer(lib().bp_msm_record_bytes(curve))
+    _check(lib().bp_msm_record_header(curve, n, window_bits, ctypes.cast(out, ctypes.c_void_p)), "bp_msm_record_header")
+    return out.raw
+
+
+def msm_multi(ctxs, points, scalars):
+    """bp_msm_g1_multi: shard i = (points[i], scalars[i]) resident with ctxs[i] (one context per device, or several on one
+    device); one host thread, no torch / RCCL.  -> the affine sum over all shards, BP_FMT_LE."""
+    k = len(ctxs)
+    A = lambda hs: (ctypes.c_void_p * k)(*[h.h for h in hs])
+    out = ctypes.create_string_buffer(ctxs[0].point_bytes)
+    _check(lib().bp_msm_g1_multi(A(ctxs), A(points), A(scalars), k, out), "bp_msm_g1_multi")
+    return out.raw
+
+
+def fr_random(curve, n=1):
+    """FieldElement::random() x n (getrandom)"""
+    out = ctypes.create_string_buffer(32 * max(1, n))
+    _check(lib().bp_fr_random(curve, out, n), "bp_fr_random")
+    return out.raw[:32 * n]
 
 
 def msm_record_bytes(curve):
@@ -609,12 +667,11 @@ class IPP:
             arr[i].transcript = tr.h
             for name, bf in zip(("P_le", "Q_le", "a_le32", "b_le32", "L_le", "R_le"), bufs):
                 setattr(arr[i], name, ctypes.cast(bf, ctypes.c_void_p))
-        if weights is None:
-            weights = b"".join(os.urandom(16) + bytes(16) for _ in range(m))
-        if len(weights) != 32 * m:
+        if weights is not None and len(weights) != 32 * m:
             raise ArgError("bp_ipp_verify_batch: need one 32-byte weight per proof")
+        # weights None: the library draws them itself (bp_fr_random)
         _check(lib().bp_ipp_verify_batch(ctx.h, n, lg_n, G_factors.h, H_factors.h, G.h, H.h, ctypes.cast(arr, ctypes.c_void_p), m,
-                                         bytes(weights) if m else b"\0"), "bp_ipp_verify_batch")
+                                         bytes(weights) if weights is not None else None), "bp_ipp_verify_batch")
 
     @staticmethod
     def verification_scalars(curve, L_le, R_le, n, transcript):
@@ -729,11 +786,12 @@ def r1cs_prove(ctx, transcript, plan, G, H, g_le, h_le, a_L, a_R, a_O, v_blindin
     return out.raw
 
 
-def r1cs_verify(ctx, transcript, plan, G, H, g_le, h_le, V_le, n, proof, r_le32):
-    """Verifier::verify (src/r1cs/verifier.rs:265-452) as one library call; raises VerificationError."""
+def r1cs_verify(ctx, transcript, plan, G, H, g_le, h_le, V_le, n, proof, r_le32=None):
+    """Verifier::verify (src/r1cs/verifier.rs:265-452) as one library call; raises VerificationError.
+    r_le32: the verifier's random weight (verifier.rs:392); None = drawn inside the library, as the reference does."""
     m = len(V_le) // ctx.point_bytes
     _check(lib().bp_r1cs_verify(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), bytes(V_le) or None, n, m, bytes(proof), len(proof),
-                                bytes(r_le32)), "bp_r1cs_verify")
+                                bytes(r_le32) if r_le32 is not None else None), "bp_r1cs_verify")
 
 
 def r1cs_prover_polys(ctx, a_L, a_R, a_O, s_L, s_R, wL, wR, wO, y_le32):

@@ -1,7 +1,6 @@
 // bp_capi.hip -- implementation of the C ABI in include/bpmsm.h (libbpmsm.so).
 // Host orchestration of the gfx950 kernels in bp_kernels.cuh; no CPU fallback for any compute entry point.
 #include <new>
-#include <thread>
 #include <vector>
 
 #include "bp_internal.hpp"
@@ -319,6 +318,8 @@ struct Impl {
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pending_W = g.tab.W;                       // _end folds with the geometry that produced the records
+        memcpy(ctx->pending_cw, g.tab.cw, sizeof ctx->pending_cw);
         ctx->pending = true;
         return BP_OK;
     }
@@ -326,11 +327,9 @@ struct Impl {
         if (!ctx->pending) return BP_ERR_ARG;
         ctx->pending = false;
         if (ctx->pending_n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
-        MsmGeom g;
-        msm_geom(g, C::Fr::BITS, ctx->pending_n, ctx->c_override);
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, g.tab.W, g.tab.cw, out_le);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, ctx->pending_W, ctx->pending_cw, out_le);
         return BP_OK;
     }
 
@@ -345,55 +344,129 @@ struct Impl {
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        // the two serial tails (~0.12 ms each: 255 dependent doublings) are independent: fold the second on another thread
+        // the two serial tails (~0.12 ms each: 255 dependent doublings) are independent: fold the second on the context's helper thread
         const host::Tail<C>& tl = tail();
         const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
-        bool spawned = false;
-        std::thread second;
-        try {
-            second = std::thread([&]() { tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le); });
-            spawned = true;
-        } catch (...) {}   // no thread available: fold both here (an exception must not cross the C ABI)
+        const bool helped = ctx->worker.submit([&]() { tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le); });
         tl.fold(rec, 1, W1, g.tab.cw, out1_le);
-        if (spawned) second.join();
-        else tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le);
+        if (helped) ctx->worker.wait();
+        else tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le);   // no thread available: fold both here
         return BP_OK;
+    }
+
+    // Record block of the two-stage (sharded) form: W window records followed by ONE header record that names the geometry
+    // which produced them, so that bp_msm_g1_finish can refuse sets that do not fit together (ranks whose shard sizes straddle
+    // a power of two pick different window widths unless the caller fixes c with bp_ctx_set_window_bits).
+    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, reserved; };   // widths: n_wide windows of cw_first bits, then cw_last
+    static_assert(sizeof(RecHeader) <= sizeof(XyzzPacked<C>), "header must fit one record");
+    static constexpr uint32_t kRecMagic = 0x31575042u;   // "BPW1"
+    static void fill_header(RecHeader& h, const MsmGeom& g) {
+        memset(&h, 0, sizeof h);
+        h.magic = kRecMagic; h.c = (uint32_t)g.c; h.W = (uint32_t)g.tab.W; h.fr_bits = (uint32_t)C::Fr::BITS;
+        h.cw_first = g.tab.cw[0]; h.cw_last = g.tab.cw[g.tab.W - 1];
+        for (int w = 0; w < g.tab.W; w++) if (g.tab.cw[w] == g.tab.cw[0]) h.n_wide++;
     }
 
     static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(device_out, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToDevice, ctx->stream));
-        // The records are about to be read by another stream (RCCL's): complete them before returning.
+        const int W = g.tab.W;
+        HIPCHK(hipMemcpyAsync(device_out, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if ((rc = host_pinned_reserve(ctx, kXyzzBytes))) return rc;
+        memset(ctx->host_pinned, 0, kXyzzBytes);
+        fill_header(*(RecHeader*)ctx->host_pinned, g);
+        HIPCHK(hipMemcpyAsync((uint8_t*)device_out + (size_t)W * kXyzzBytes, ctx->host_pinned, kXyzzBytes, hipMemcpyHostToDevice, ctx->stream));
+        // The records are about to be read by another stream (RCCL's) or another device: complete them before returning.
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
         return BP_OK;
+    }
+
+    // host_rec: sets x (W + 1) records in host memory (header last in each set); validates the headers and folds
+    static int finish_host(int c_override, const XyzzPacked<C>* host_rec, size_t sets, size_t n_per_set, uint8_t* out_le) {
+        MsmGeom g;
+        msm_geom(g, C::Fr::BITS, n_per_set, c_override);
+        const int W = g.tab.W;
+        RecHeader want;
+        fill_header(want, g);
+        std::vector<XyzzPacked<C>> packed(sets * (size_t)W);
+        for (size_t s = 0; s < sets; s++) {
+            const XyzzPacked<C>* set = host_rec + s * (size_t)(W + 1);
+            if (memcmp(&set[W], &want, sizeof want) != 0) return BP_ERR_ARG;     // geometry of this set differs from the caller's
+            memcpy(&packed[s * (size_t)W], set, (size_t)W * kXyzzBytes);
+        }
+        tail().fold(packed.data(), sets, W, g.tab.cw, out_le);
+        return BP_OK;
+    }
+
+    // bp_msm_g1_multi, device half of one shard: queue the pipeline with the shared window width c and the D2H copy of the W
+    // window sums into this context's pinned buffer; no synchronisation.
+    static int multi_begin(bp_ctx* ctx, const bp_g1vec* pts, const bp_frvec* sc, int c, int* W_out) {
+        const int saved = ctx->c_override;
+        ctx->c_override = c;
+        MsmGeom g;
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts->d, (const ScalarWords*)sc->d, pts->n, g);
+        ctx->c_override = saved;
+        if (rc) return rc;
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        *W_out = g.tab.W;
+        return BP_OK;
+    }
+
+    // one affine point (canonical LE) -> a packed XYZZ record in the device's Montgomery radix (host arithmetic)
+    static void record_from_affine(const uint8_t* le, XyzzPacked<C>* out) {
+        uint32_t xw[Fp::NW], yw[Fp::NW];
+        memcpy(xw, le, 4 * Fp::NW);
+        memcpy(yw, le + 4 * Fp::NW, 4 * Fp::NW);
+        Aff<C> a;
+        a.x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
+        a.y = fe_to_mont<Fp>(fe_unpack_words<Fp>(yw));
+        *out = xyzz_pack(xyzz_from_aff(a));
     }
 
     static int msm_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
         MsmGeom g;
         msm_geom(g, C::Fr::BITS, n_per_set, ctx->c_override);
-        size_t bytes = sets * (size_t)g.tab.W * kXyzzBytes;
+        size_t bytes = sets * (size_t)(g.tab.W + 1) * kXyzzBytes;
         int rc;
         if ((rc = host_pinned_reserve(ctx, bytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, device_records, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, sets, g.tab.W, g.tab.cw, out_le);
-        return BP_OK;
+        return finish_host(ctx->c_override, (const XyzzPacked<C>*)ctx->host_pinned, sets, n_per_set, out_le);
     }
 
-    static int upload_points(bp_ctx* ctx, const uint8_t* le, size_t n, void* d_out) {
+    // validate = true: BP_ERR_ARG if a coordinate is >= p or a point is off the curve (see k_points_to_resident)
+    static int upload_points(bp_ctx* ctx, const uint8_t* le, size_t n, void* d_out, bool validate) {
         size_t bytes = n * 2 * 4 * Fp::NW;
         int rc;
         if ((rc = ctx->scratch.reserve(bytes ? bytes : 16))) return rc;
+        if ((rc = ctx->flags.reserve(64))) return rc;
+        uint32_t* flag = validate ? (uint32_t*)ctx->flags.p : nullptr;
+        uint32_t host_flag = 0;
+        if (flag) HIPCHK(hipMemsetAsync(flag, 0, 4, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->scratch.p, le, bytes, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_points_to_resident<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
-                           (const uint32_t*)ctx->scratch.p, n, (AffPacked<C>*)d_out);
+                           (const uint32_t*)ctx->scratch.p, n, (AffPacked<C>*)d_out, flag);
         HIPCHK(hipGetLastError());
+        if (flag) HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));   // `le` is a borrowed host buffer
-        return BP_OK;
+        return host_flag ? BP_ERR_ARG : BP_OK;
+    }
+
+    static int check_scalars(bp_ctx* ctx, const void* d_sc, size_t n) {
+        int rc;
+        if ((rc = ctx->flags.reserve(64))) return rc;
+        uint32_t* flag = (uint32_t*)ctx->flags.p;
+        uint32_t host_flag = 0;
+        HIPCHK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_check_scalars<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)d_sc, n, flag);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return host_flag ? BP_ERR_ARG : BP_OK;
     }
 
     static int download_points(bp_ctx* ctx, const void* d_in, size_t offset, size_t n, uint8_t* le) {
@@ -511,6 +584,9 @@ int bp_ctx_create(int curve_id, int device_ordinal, bp_ctx** out) {
     ctx->device = device_ordinal;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BP_ERR_DEVICE; }
     ctx->stream = ctx->own_stream;
+    ctx->pool = new (std::nothrow) DevPool();
+    if (!ctx->pool) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return BP_ERR_DEVICE; }
+    ctx->pool->device = device_ordinal;
     *out = ctx;
     return BP_OK;
 }
@@ -521,7 +597,8 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->fixed_base_table.release();
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_code, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
-                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch}) b->release();
+                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags}) b->release();
+    if (ctx->pool) ctx->pool->release();     // cached blocks go back to the driver; live handles keep the pool itself alive
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->ev_ready) for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -531,7 +608,12 @@ int bp_ctx_destroy(bp_ctx* ctx) {
 
 int bp_ctx_set_stream(bp_ctx* ctx, void* hip_stream) {
     if (!ctx) return BP_ERR_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream) {   // pool blocks are recycled in stream order: drain the old stream before work moves to another
+        int rc = set_device(ctx); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->stream = next;
     return BP_OK;
 }
 
@@ -574,11 +656,11 @@ int bp_g1vec_alloc(bp_ctx* ctx, size_t n, bp_g1vec** out) {
     if (!ctx || !out) return BP_ERR_ARG;
     *out = nullptr;
     int rc = set_device(ctx); if (rc) return rc;
-    void* d = nullptr;
-    size_t bytes = (n ? n : 1) * point_bytes(ctx);
-    HIPCHK(hipMalloc(&d, bytes));
-    if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(d); return BP_ERR_DEVICE; }
-    *out = new bp_g1vec{ctx, d, n, true, ctx->device};
+    size_t bytes = (n ? n : 1) * point_bytes(ctx), cap = 0;
+    void* d = ctx->pool->get(bytes, &cap);
+    if (!d) return BP_ERR_DEVICE;
+    if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { ctx->pool->put(d, cap); return BP_ERR_DEVICE; }
+    *out = new bp_g1vec{ctx, d, n, true, ctx->device, ctx->pool, cap};
     return BP_OK;
 }
 
@@ -603,8 +685,8 @@ int bp_g1vec_upload(bp_ctx* ctx, const uint8_t* points, size_t n, int fmt, bp_g1
         }
         src = le.data();
     }
-    if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::upload_points(ctx, src, n, (*out)->d);
-    else rc = Impl<Bn254>::upload_points(ctx, src, n, (*out)->d);
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = Impl<Bls381>::upload_points(ctx, src, n, (*out)->d, true);
+    else rc = Impl<Bn254>::upload_points(ctx, src, n, (*out)->d, true);
     if (rc) { bp_g1vec_free(*out); *out = nullptr; }
     return rc;
 }
@@ -638,7 +720,7 @@ int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, i
 
 int bp_g1vec_free(bp_g1vec* v) {
     if (!v) return BP_OK;
-    if (v->owned && v->d) { (void)hipSetDevice(v->device); (void)hipFree(v->d); }
+    if (v->owned && v->d) v->pool->put(v->d, v->cap);     // back to the context's pool (no device synchronisation)
     delete v;
     return BP_OK;
 }
@@ -648,7 +730,7 @@ void* bp_g1vec_device_ptr(bp_g1vec* v) { return v ? v->d : nullptr; }
 
 int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out) {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
-    *out = new bp_g1vec{ctx, device_ptr, n, false, ctx->device};
+    *out = new bp_g1vec{ctx, device_ptr, n, false, ctx->device, nullptr, 0};
     return BP_OK;
 }
 
@@ -674,11 +756,11 @@ int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out) {
     if (!ctx || !out) return BP_ERR_ARG;
     *out = nullptr;
     int rc = set_device(ctx); if (rc) return rc;
-    void* d = nullptr;
-    size_t bytes = (n ? n : 1) * 32;
-    HIPCHK(hipMalloc(&d, bytes));
-    if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(d); return BP_ERR_DEVICE; }
-    *out = new bp_frvec{ctx, d, n, true, ctx->device};
+    size_t bytes = (n ? n : 1) * 32, cap = 0;
+    void* d = ctx->pool->get(bytes, &cap);
+    if (!d) return BP_ERR_DEVICE;
+    if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { ctx->pool->put(d, cap); return BP_ERR_DEVICE; }
+    *out = new bp_frvec{ctx, d, n, true, ctx->device, ctx->pool, cap};
     return BP_OK;
 }
 
@@ -687,11 +769,14 @@ int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec
     int rc = bp_frvec_alloc(ctx, n, out);
     if (rc) return rc;
     if (n == 0) return BP_OK;
-    if (hipMemcpyAsync((*out)->d, scalars_le32, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (hipMemcpyAsync((*out)->d, scalars_le32, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
         bp_frvec_free(*out); *out = nullptr; return BP_ERR_DEVICE;
     }
-    return BP_OK;
+    // canonical scalars only (< r): the window recoding silently wraps otherwise.  The check also completes the copy of the
+    // borrowed host buffer (it ends with a stream synchronisation).
+    rc = ctx->curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::check_scalars(ctx, (*out)->d, n) : Impl<Bn254>::check_scalars(ctx, (*out)->d, n);
+    if (rc) { bp_frvec_free(*out); *out = nullptr; }
+    return rc;
 }
 
 int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, uint8_t* out_le32) {
@@ -715,7 +800,7 @@ int bp_frvec_copy(bp_ctx* ctx, bp_frvec* dst, size_t dst_off, const bp_frvec* sr
 
 int bp_frvec_free(bp_frvec* v) {
     if (!v) return BP_OK;
-    if (v->owned && v->d) { (void)hipSetDevice(v->device); (void)hipFree(v->d); }
+    if (v->owned && v->d) v->pool->put(v->d, v->cap);
     delete v;
     return BP_OK;
 }
@@ -725,7 +810,7 @@ void* bp_frvec_device_ptr(bp_frvec* v) { return v ? v->d : nullptr; }
 
 int bp_frvec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_frvec** out) {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
-    *out = new bp_frvec{ctx, device_ptr, n, false, ctx->device};
+    *out = new bp_frvec{ctx, device_ptr, n, false, ctx->device, nullptr, 0};
     return BP_OK;
 }
 
@@ -768,7 +853,7 @@ size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {
     int bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
     MsmGeom g;
     msm_geom(g, bits, n, ctx->c_override);
-    return (size_t)g.tab.W;
+    return (size_t)g.tab.W + 1;   // W window records + the geometry header (see RecHeader)
 }
 
 size_t bp_msm_record_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? sizeof(XyzzPacked<Bls381>) : sizeof(XyzzPacked<Bn254>); }
@@ -784,6 +869,104 @@ int bp_msm_g1_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_
     if (!ctx || !device_records || !out_le || sets == 0 || n_per_set == 0) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
     DISPATCH(ctx, I::msm_finish(ctx, device_records, sets, n_per_set, out_le));
+}
+
+int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, size_t n_per_set, int window_bits, uint8_t* out_le) {
+    if (!curve_ok(curve_id) || !host_records || !out_le || sets == 0 || n_per_set == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) return Impl<Bls381>::finish_host(window_bits, (const XyzzPacked<Bls381>*)host_records, sets, n_per_set, out_le);
+    return Impl<Bn254>::finish_host(window_bits, (const XyzzPacked<Bn254>*)host_records, sets, n_per_set, out_le);
+}
+
+int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32) {
+    if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    MsmGeom g;
+    msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits);
+    if (c_out) *c_out = g.c;
+    if (W_out) *W_out = g.tab.W;
+    for (int w = 0; w < g.tab.W; w++) { if (cw_out) cw_out[w] = g.tab.cw[w]; if (off_out) off_out[w] = g.tab.off[w]; }
+    if (bias_le32) memcpy(bias_le32, g.tab.bias.w, 32);
+    return BP_OK;
+}
+
+int bp_msm_record_from_affine(int curve_id, const uint8_t* point_le, void* record_out) {
+    if (!curve_ok(curve_id) || !point_le || !record_out) return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) Impl<Bls381>::record_from_affine(point_le, (XyzzPacked<Bls381>*)record_out);
+    else Impl<Bn254>::record_from_affine(point_le, (XyzzPacked<Bn254>*)record_out);
+    return BP_OK;
+}
+
+int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_out) {
+    if (!curve_ok(curve_id) || !record_out || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    MsmGeom g;
+    msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits);
+    memset(record_out, 0, bp_msm_record_bytes(curve_id));
+    if (curve_id == BP_CURVE_BLS12_381) Impl<Bls381>::fill_header(*(Impl<Bls381>::RecHeader*)record_out, g);
+    else Impl<Bn254>::fill_header(*(Impl<Bn254>::RecHeader*)record_out, g);
+    return BP_OK;
+}
+
+// One host thread, several devices (or several contexts on one device), no RCCL: shard i = (points[i], scalars[i]) lives with
+// ctxs[i].  Every shard's device stage is queued from its context's helper thread (launch overhead in parallel), all with ONE
+// window width so that the records fit together; each device copies its W window sums (W x 192 B) to pinned host memory and
+// the calling thread folds the N record sets.  The "reduce" of north_star is this gather: N x 3 KiB, latency-bound.
+int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp_frvec* const* scalars, size_t n_shards, uint8_t* out_le) {
+    if (!ctxs || !points || !scalars || !out_le || n_shards == 0 || n_shards > 64) return BP_ERR_ARG;
+    size_t n_max = 0;
+    for (size_t i = 0; i < n_shards; i++) {
+        if (!ctxs[i] || !points[i] || !scalars[i] || ctxs[i]->curve != ctxs[0]->curve) return BP_ERR_ARG;
+        if (points[i]->n != scalars[i]->n) return BP_ERR_LENGTH;
+        for (size_t j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) return BP_ERR_ARG;      // one shard in flight per context
+        if (points[i]->n > n_max) n_max = points[i]->n;
+    }
+    const int curve = ctxs[0]->curve;
+    const size_t pbytes = 2 * (size_t)fp_bytes_of(curve);
+    if (n_max == 0) { memset(out_le, 0, pbytes); return BP_OK; }
+    MsmGeom g;
+    msm_geom(g, curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n_max, ctxs[0]->c_override);
+    const int c = g.c, W = g.tab.W;
+    std::vector<int> rcs(n_shards, BP_OK), Ws(n_shards, W);
+    std::vector<char> queued(n_shards, 0), live(n_shards, 0);
+    for (size_t i = 0; i < n_shards; i++) {
+        if (points[i]->n == 0) continue;
+        live[i] = 1;
+        auto job = [&, i]() {
+            bp_ctx* cx = ctxs[i];
+            int rc = set_device(cx);
+            if (!rc) rc = curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::multi_begin(cx, points[i], scalars[i], c, &Ws[i])
+                                                      : Impl<Bn254>::multi_begin(cx, points[i], scalars[i], c, &Ws[i]);
+            rcs[i] = rc;
+        };
+        if (n_shards > 1 && ctxs[i]->worker.submit(job)) queued[i] = 1;
+        else job();
+    }
+    for (size_t i = 0; i < n_shards; i++) if (queued[i]) ctxs[i]->worker.wait();
+    int rc = BP_OK;
+    for (size_t i = 0; i < n_shards; i++) {
+        if (!live[i]) continue;
+        if (!rcs[i] && Ws[i] != W) rcs[i] = BP_ERR_DEVICE;
+        if (set_device(ctxs[i]) != BP_OK || hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) rcs[i] = rcs[i] ? rcs[i] : BP_ERR_DEVICE;
+        if (rcs[i] && !rc) rc = rcs[i];
+    }
+    if (rc) return rc;
+    const size_t rec = bp_msm_record_bytes(curve);
+    std::vector<uint8_t> all;
+    size_t sets = 0;
+    for (size_t i = 0; i < n_shards; i++) {
+        if (!live[i]) continue;
+        all.insert(all.end(), (const uint8_t*)ctxs[i]->host_pinned, (const uint8_t*)ctxs[i]->host_pinned + (size_t)W * rec);
+        sets++;
+    }
+    if (curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().fold((const XyzzPacked<Bls381>*)all.data(), sets, W, g.tab.cw, out_le);
+    else Impl<Bn254>::tail().fold((const XyzzPacked<Bn254>*)all.data(), sets, W, g.tab.cw, out_le);
+    return BP_OK;
+}
+
+int bp_ctx_trim(bp_ctx* ctx) {
+    if (!ctx) return BP_ERR_ARG;
+    int rc = set_device(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->pool->trim();
+    return BP_OK;
 }
 
 }  // extern "C"

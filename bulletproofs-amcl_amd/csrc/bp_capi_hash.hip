@@ -48,21 +48,21 @@ int hash_common(bp_ctx* ctx, const uint8_t* bytes, size_t nbytes, const uint64_t
     if (rc) return rc;
     if (n == 0) return BP_OK;
     // staging: [next-message counter (8 B) | message bytes]; offsets separately (8-byte aligned)
-    void *d_stage = nullptr, *d_offs = nullptr;
-    auto fail = [&](int code) { if (d_stage) (void)hipFree(d_stage); if (d_offs) (void)hipFree(d_offs); bp_g1vec_free(*out); *out = nullptr; return code; };
-    if (hipMalloc(&d_stage, 8 + (nbytes ? nbytes : 1)) != hipSuccess) return fail(BP_ERR_DEVICE);
+    PoolBlock b_stage, b_offs;
+    auto fail = [&](int code) { bp_g1vec_free(*out); *out = nullptr; return code; };
+    if (!b_stage.alloc(ctx, 8 + (nbytes ? nbytes : 1))) return fail(BP_ERR_DEVICE);
+    void *d_stage = b_stage.p, *d_offs = nullptr;
     uint8_t* d_bytes = (uint8_t*)d_stage + 8;
     if (nbytes && hipMemcpyAsync(d_bytes, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(BP_ERR_DEVICE);
     if (offs) {
-        if (hipMalloc(&d_offs, (n + 1) * sizeof(uint64_t)) != hipSuccess) return fail(BP_ERR_DEVICE);
+        if (!b_offs.alloc(ctx, (n + 1) * sizeof(uint64_t))) return fail(BP_ERR_DEVICE);
+        d_offs = b_offs.p;
         if (hipMemcpyAsync(d_offs, offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(BP_ERR_DEVICE);
     }
     if (ctx->curve == BP_CURVE_BLS12_381) rc = launch_hash<Bls381>(ctx, d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (unsigned long long*)d_stage, (*out)->d);
     else rc = launch_hash<Bn254>(ctx, d_bytes, (const uint64_t*)d_offs, (uint32_t)nbytes, first, n, (unsigned long long*)d_stage, (*out)->d);
     if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_DEVICE;
     if (rc) return fail(rc);
-    (void)hipFree(d_stage);
-    if (d_offs) (void)hipFree(d_offs);
     return BP_OK;
 }
 

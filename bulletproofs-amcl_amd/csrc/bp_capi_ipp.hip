@@ -1,6 +1,8 @@
 // bp_capi_ipp.hip -- C ABI (include/bpmsm.h) for the FieldElementVector helpers, the host transcript and the
 // inner-product argument.  Host orchestration mirrors /root/reference src/ipp.rs:35-315 and src/transcript.rs:29-61;
 // all per-element work runs in the kernels of bp_ipp.cuh, the MSMs in the bucket pipeline of bp_capi.hip.
+#include <errno.h>
+#include <sys/random.h>
 #include <new>
 #include <vector>
 
@@ -29,6 +31,17 @@ struct bp_ipp_state {
     bool fold_generators;
     void *Pall, *cG, *cH, *sL, *sR;
     int device;
+    // every buffer above is a block of the context's pool (recycled, no hipMalloc / hipFree per proof)
+    DevPool* pool;
+    std::vector<std::pair<void*, size_t>>* blocks;
+    bool take(void** out, size_t bytes) {
+        size_t cap = 0;
+        void* p = pool->get(bytes ? bytes : 1, &cap);
+        if (!p) return false;
+        blocks->push_back({p, cap});
+        *out = p;
+        return true;
+    }
 };
 
 // flattened_constraints plan: the circuit's terms grouped by destination (CSR), resident on the device
@@ -248,10 +261,14 @@ struct Ipp {
         int rc = verification_scalars(t, L_le, R_le, lg_n, n, ch, ch_inv);              // :218
         if (rc) return rc;
         size_t m = 1 + 2 * n + 2 * lg_n;
-        void *pts = nullptr, *sc = nullptr, *chd = nullptr, *raw = nullptr;
-        auto cleanup = [&]() { if (pts) (void)hipFree(pts); if (sc) (void)hipFree(sc); if (chd) (void)hipFree(chd); if (raw) (void)hipFree(raw); };
-        if (hipMalloc(&pts, m * kPt) != hipSuccess || hipMalloc(&sc, m * 32) != hipSuccess || hipMalloc(&chd, (2 * lg_n + 1) * 32) != hipSuccess ||
-            hipMalloc(&raw, (2 * lg_n + 1) * 2 * kFb) != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+        PoolBlock b_pts, b_sc, b_chd, b_raw;      // recycled through the context's pool (no hipMalloc / hipFree per proof)
+        if (!b_pts.alloc(ctx, m * kPt) || !b_sc.alloc(ctx, m * 32) || !b_chd.alloc(ctx, (2 * lg_n + 1) * 32) || !b_raw.alloc(ctx, (2 * lg_n + 1) * 2 * kFb))
+            return BP_ERR_DEVICE;
+        void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
+        auto cleanup = [&]() {};
+        if ((rc = ctx->flags.reserve(64))) return rc;
+        uint32_t* flag = (uint32_t*)ctx->flags.p;     // Q, L, R come from the proof: validated (on the curve, canonical)
+        uint32_t host_flag = 0;
         // challenges (Montgomery form) for the per-element products
         std::vector<ScalarWords> hch(2 * lg_n + 1);
         for (size_t j = 0; j < lg_n; j++) { hch[j] = fr_mont_words<F>(ch[j]); hch[lg_n + j] = fr_mont_words<F>(ch_inv[j]); }
@@ -269,16 +286,18 @@ struct Ipp {
         memcpy(hraw.data(), Q_le, 2 * kFb);
         if (lg_n) { memcpy(hraw.data() + 2 * kFb, L_le, lg_n * 2 * kFb); memcpy(hraw.data() + (1 + lg_n) * 2 * kFb, R_le, lg_n * 2 * kFb); }
         hipStream_t s = ctx->stream;
-        bool ok = hipMemcpyAsync(chd, hch.data(), 2 * lg_n * 32 + 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+        bool ok = hipMemsetAsync(flag, 0, 4, s) == hipSuccess &&
+                  hipMemcpyAsync(chd, hch.data(), 2 * lg_n * 32 + 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(sc, ends.data(), 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   (lg_n == 0 || hipMemcpyAsync((uint8_t*)sc + (1 + 2 * n) * 32, ends.data() + 1, 2 * lg_n * 32, hipMemcpyHostToDevice, s) == hipSuccess);
         if (!ok) { cleanup(); return BP_ERR_DEVICE; }
         // Q -> pts[0]; L,R -> pts[1+2n ..]
-        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)raw, (size_t)1, (AffPacked<C>*)pts);
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)raw, (size_t)1, (AffPacked<C>*)pts, flag);
         if (lg_n)
             hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(2 * lg_n)), dim3(kBlock), 0, s, (const uint32_t*)((uint8_t*)raw + 2 * kFb),
-                               2 * lg_n, (AffPacked<C>*)pts + 1 + 2 * n);
+                               2 * lg_n, (AffPacked<C>*)pts + 1 + 2 * n, flag);
+        if (hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return BP_ERR_DEVICE;
         hipLaunchKernelGGL(k_ipp_verify_terms<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
                            (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, (const ScalarWords*)chd, (const ScalarWords*)chd + lg_n, (int)lg_n,
                            fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)pts, (ScalarWords*)sc);
@@ -286,8 +305,8 @@ struct Ipp {
         uint8_t expect[2 * kFb];
         rc = bp_internal_msm(ctx, pts, sc, m, expect);                                  // :251-253
         if (hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : BP_ERR_DEVICE;
-        cleanup();
         if (rc) return rc;
+        if (host_flag) return BP_ERR_VERIFY;                                            // a proof point that is not a curve point
         return memcmp(expect, P_le, 2 * kFb) == 0 ? BP_OK : BP_ERR_VERIFY;              // :255-259
     }
 
@@ -330,21 +349,27 @@ struct Ipp {
             put(1 + 2 * lg_n, fe_neg(w));                                                // -w        on P
             memcpy(rw + (1 + 2 * lg_n) * 2 * kFb, pr.P_le, 2 * kFb);
         }
-        void *pts = nullptr, *sc = nullptr, *chd = nullptr, *raw = nullptr;
-        auto cleanup = [&]() { if (pts) (void)hipFree(pts); if (sc) (void)hipFree(sc); if (chd) (void)hipFree(chd); if (raw) (void)hipFree(raw); };
         const size_t nch = hch.size();
-        if (hipMalloc(&pts, total * kPt) != hipSuccess || hipMalloc(&sc, total * 32) != hipSuccess ||
-            hipMalloc(&chd, (2 * nch + 2 * m) * 32) != hipSuccess || hipMalloc(&raw, hraw.size()) != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+        PoolBlock b_pts, b_sc, b_chd, b_raw;
+        if (!b_pts.alloc(ctx, total * kPt) || !b_sc.alloc(ctx, total * 32) || !b_chd.alloc(ctx, (2 * nch + 2 * m) * 32) || !b_raw.alloc(ctx, hraw.size()))
+            return BP_ERR_DEVICE;
+        void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
+        auto cleanup = [&]() {};
+        { int rcf = ctx->flags.reserve(64); if (rcf) return rcf; }
+        uint32_t* flag = (uint32_t*)ctx->flags.p;
+        uint32_t host_flag = 0;
         ScalarWords *d_ch = (ScalarWords*)chd, *d_chi = d_ch + nch, *d_wa = d_chi + nch, *d_wb = d_wa + m;
         hipStream_t s = ctx->stream;
-        bool ok = hipMemcpyAsync(d_ch, hch.data(), nch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+        bool ok = hipMemsetAsync(flag, 0, 4, s) == hipSuccess &&
+                  hipMemcpyAsync(d_ch, hch.data(), nch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(d_chi, hchi.data(), nch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(d_wa, hwa.data(), m * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(d_wb, hwb.data(), m * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync((uint8_t*)sc + 2 * n * 32, tail.data(), m * per * 32, hipMemcpyHostToDevice, s) == hipSuccess;
         if (!ok) { cleanup(); return BP_ERR_DEVICE; }
-        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(m * per)), dim3(kBlock), 0, s, (const uint32_t*)raw, m * per, (AffPacked<C>*)pts + 2 * n);
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(m * per)), dim3(kBlock), 0, s, (const uint32_t*)raw, m * per, (AffPacked<C>*)pts + 2 * n, flag);
+        if (hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return BP_ERR_DEVICE;
         hipLaunchKernelGGL(k_ipp_verify_terms_batch<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
                            (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, d_ch, d_chi, d_wa, d_wb, (int)lg_n, m, n, (AffPacked<C>*)pts,
                            (ScalarWords*)sc);
@@ -352,8 +377,8 @@ struct Ipp {
         uint8_t got[2 * kFb];
         int rc = bp_internal_msm(ctx, pts, sc, total, got);
         if (hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : BP_ERR_DEVICE;
-        cleanup();
         if (rc) return rc;
+        if (host_flag) return BP_ERR_VERIFY;
         for (size_t k = 0; k < 2 * kFb; k++) if (got[k]) return BP_ERR_VERIFY;          // identity = all-zero bytes
         return BP_OK;
     }
@@ -425,9 +450,10 @@ static int r1cs_verifier_scalars_impl(bp_ctx* ctx, Transcript& t, const uint8_t*
 template <class C>
 static int flattened_constraints_impl(bp_ctx* ctx, const bp_r1cs_plan* p, const uint8_t* z_le32, bp_frvec* outv[4], uint8_t* wc_le32) {
     using F = typename C::Fr;
-    void *zp = nullptr, *all = nullptr;
-    auto cleanup = [&]() { if (zp) (void)hipFree(zp); if (all) (void)hipFree(all); };
-    if (hipMalloc(&zp, (p->nq ? p->nq : 1) * 32) != hipSuccess || hipMalloc(&all, p->ndest * 32) != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+    PoolBlock b_zp, b_all;
+    if (!b_zp.alloc(ctx, (p->nq ? p->nq : 1) * 32) || !b_all.alloc(ctx, p->ndest * 32)) return BP_ERR_DEVICE;
+    void *zp = b_zp.p, *all = b_all.p;
+    auto cleanup = [&]() {};
     hipStream_t s = ctx->stream;
     if (p->nq) hipLaunchKernelGGL(k_fr_powers_mont<C>, dim3(blocks_for(p->nq)), dim3(kBlock), 0, s, fr_mont_words<F>(fr_from_le<F>(z_le32)), p->nq, (ScalarWords*)zp);
     hipLaunchKernelGGL(k_r1cs_flatten<C>, dim3(blocks_for(p->ndest)), dim3(kBlock), 0, s, (const uint32_t*)p->seg, (const uint32_t*)p->tq,
@@ -520,6 +546,38 @@ int bp_fr_inverse(int curve_id, const uint8_t* in_le32, uint8_t* out_le32) {
     if (curve_id == BP_CURVE_BLS12_381) fr_to_le<Bls381Fr>(fe_inv<Bls381Fr>(fr_from_le<Bls381Fr>(in_le32)), out_le32);
     else fr_to_le<Bn254Fr>(fe_inv<Bn254Fr>(fr_from_le<Bn254Fr>(in_le32)), out_le32);
     return BP_OK;
+}
+
+// FieldElement::random() (src/r1cs/verifier.rs:392 and the provers' blindings): n uniform non-zero scalars from the OS
+// (getrandom), by rejection of fr_bits-bit draws.
+int bp_fr_random(int curve_id, uint8_t* out_le32, size_t n) {
+    if (!curve_ok(curve_id) || (!out_le32 && n)) return BP_ERR_ARG;
+    const int bits = curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = out_le32 + 32 * i;
+        for (int tries = 0;; tries++) {
+            if (tries > 1000) return BP_ERR_DEVICE;
+            size_t got = 0;
+            while (got < 32) {
+                ssize_t k = getrandom(o + got, 32 - got, 0);
+                if (k < 0) { if (errno == EINTR) continue; return BP_ERR_DEVICE; }
+                got += (size_t)k;
+            }
+            if (bits < 256) o[31] &= (uint8_t)((1u << (bits - 248)) - 1);
+            if (bp_fr_is_canonical_nonzero(curve_id, o)) break;
+        }
+    }
+    return BP_OK;
+}
+
+int bp_fr_is_canonical_nonzero(int curve_id, const uint8_t* x_le32) {
+    if (!curve_ok(curve_id) || !x_le32) return 0;
+    uint32_t w[8];
+    memcpy(w, x_le32, 32);
+    uint32_t any = 0;
+    for (int i = 0; i < 8; i++) any |= w[i];
+    if (!any) return 0;
+    return curve_id == BP_CURVE_BLS12_381 ? (int)words_lt_mod<Bls381Fr>(w) : (int)words_lt_mod<Bn254Fr>(w);
 }
 
 // ---- FieldElementVector kernels -----------------------------------------------------------------------------
@@ -715,9 +773,10 @@ int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le,
 // ---- IPP device-resident state ------------------------------------------------------------------------------
 int bp_ipp_state_free(bp_ipp_state* st) {
     if (!st) return BP_OK;
-    (void)hipSetDevice(st->device);
-    for (void* p : {st->G, st->H, st->a, st->b, st->gf, st->hf, st->Q, st->pts_tmp, st->sc_tmp, st->cLR, st->partial, st->Pall, st->cG, st->cH, st->sL,
-                    st->sR}) if (p) (void)hipFree(p);
+    if (st->blocks) {
+        for (auto& b : *st->blocks) st->pool->put(b.first, b.second);
+        delete st->blocks;
+    }
     delete st;
     return BP_OK;
 }
@@ -736,10 +795,15 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     memset(st, 0, sizeof *st);
     st->ctx = ctx; st->n0 = st->n = n; st->first = true; st->device = ctx->device;
     st->fold_generators = ctx->ipp_fold_generators;
+    st->pool = ctx->pool;
+    st->blocks = new (std::nothrow) std::vector<std::pair<void*, size_t>>();
+    if (!st->blocks) { delete st; return BP_ERR_DEVICE; }
     hipStream_t s = ctx->stream;
-    bool ok = hipMalloc(&st->a, n * 32) == hipSuccess && hipMalloc(&st->b, n * 32) == hipSuccess && hipMalloc(&st->cLR, 64) == hipSuccess &&
-              hipMalloc(&st->partial, (kInnerBlocks + 1) * 32) == hipSuccess && hipMalloc(&st->Q, pt) == hipSuccess &&
-              hipMalloc(&st->pts_tmp, 2 * (n + 1) * pt) == hipSuccess;
+    if ((rc = ctx->flags.reserve(64))) { bp_ipp_state_free(st); return rc; }
+    uint32_t* flag = (uint32_t*)ctx->flags.p;
+    uint32_t host_flag = 0;
+    bool ok = st->take(&st->a, n * 32) && st->take(&st->b, n * 32) && st->take(&st->cLR, 64) && st->take(&st->partial, (kInnerBlocks + 1) * 32) &&
+              st->take(&st->Q, pt) && st->take(&st->pts_tmp, 2 * (n + 1) * pt) && hipMemsetAsync(flag, 0, 4, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(st->a, a->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&                       // clones, ipp.rs:57-60
          hipMemcpyAsync(st->b, b->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess;
     if (ok) {
@@ -747,16 +811,18 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
         ok = hipMemcpyAsync(st->pts_tmp, Q_le, pt, hipMemcpyHostToDevice, s) == hipSuccess;
         if (ok) {
             if (ctx->curve == BP_CURVE_BLS12_381)
-                hipLaunchKernelGGL(k_points_to_resident<Bls381>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)st->pts_tmp, (size_t)1, (AffPacked<Bls381>*)st->Q);
+                hipLaunchKernelGGL(k_points_to_resident<Bls381>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)st->pts_tmp, (size_t)1, (AffPacked<Bls381>*)st->Q, flag);
             else
-                hipLaunchKernelGGL(k_points_to_resident<Bn254>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)st->pts_tmp, (size_t)1, (AffPacked<Bn254>*)st->Q);
-            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                hipLaunchKernelGGL(k_points_to_resident<Bn254>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)st->pts_tmp, (size_t)1, (AffPacked<Bn254>*)st->Q, flag);
+            ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+            if (ok && host_flag) { bp_ipp_state_free(st); return BP_ERR_ARG; }      // Q is not a point of the curve
         }
     }
     if (ok && st->fold_generators) {
         // reference-shaped mode: working copies of G, H are folded in place every round (k_ipp_fold)
-        ok = hipMalloc(&st->G, n * pt) == hipSuccess && hipMalloc(&st->H, n * pt) == hipSuccess && hipMalloc(&st->gf, n * 32) == hipSuccess &&
-             hipMalloc(&st->hf, n * 32) == hipSuccess && hipMalloc(&st->sc_tmp, 2 * (n + 1) * 32) == hipSuccess &&
+        ok = st->take(&st->G, n * pt) && st->take(&st->H, n * pt) && st->take(&st->gf, n * 32) && st->take(&st->hf, n * 32) &&
+             st->take(&st->sc_tmp, 2 * (n + 1) * 32) &&
              hipMemcpyAsync(st->G, G->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
              hipMemcpyAsync(st->H, H->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
              hipMemcpyAsync(st->gf, Gf->d, n * 32, hipMemcpyDeviceToDevice, s) == hipSuccess &&
@@ -764,8 +830,7 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     } else if (ok) {
         // default: [G | H | Q] resident and never modified; coefficients start as the factors
         size_t m = 2 * n + 1;
-        ok = hipMalloc(&st->Pall, m * pt) == hipSuccess && hipMalloc(&st->cG, n * 32) == hipSuccess && hipMalloc(&st->cH, n * 32) == hipSuccess &&
-             hipMalloc(&st->sL, m * 32) == hipSuccess && hipMalloc(&st->sR, m * 32) == hipSuccess &&
+        ok = st->take(&st->Pall, m * pt) && st->take(&st->cG, n * 32) && st->take(&st->cH, n * 32) && st->take(&st->sL, m * 32) && st->take(&st->sR, m * 32) &&
              hipMemcpyAsync(st->Pall, G->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
              hipMemcpyAsync((uint8_t*)st->Pall + n * pt, H->d, n * pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
              hipMemcpyAsync((uint8_t*)st->Pall + 2 * n * pt, st->Q, pt, hipMemcpyDeviceToDevice, s) == hipSuccess &&
@@ -834,7 +899,17 @@ int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_fac
 
 int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
                         const bp_g1vec* H, const bp_ipp_proof_ref* proofs, size_t m, const uint8_t* weights_le32) {
-    if (!ctx || !G_factors || !H_factors || !G || !H || (m && (!proofs || !weights_le32))) return BP_ERR_ARG;
+    if (!ctx || !G_factors || !H_factors || !G || !H || (m && !proofs)) return BP_ERR_ARG;
+    // weights: the caller's (tests) or, with NULL, fresh ones from the OS; a zero weight would drop its proof from the check
+    std::vector<uint8_t> wbuf;
+    if (m && !weights_le32) {
+        wbuf.resize(m * 32);
+        int rcw = bp_fr_random(ctx->curve, wbuf.data(), m);
+        if (rcw) return rcw;
+        weights_le32 = wbuf.data();
+    } else {
+        for (size_t p = 0; p < m; p++) if (!bp_fr_is_canonical_nonzero(ctx->curve, weights_le32 + 32 * p)) return BP_ERR_ARG;
+    }
     for (size_t p = 0; p < m; p++) {
         const bp_ipp_proof_ref& r = proofs[p];
         if (!r.transcript || !r.P_le || !r.Q_le || !r.a_le32 || !r.b_le32 || (lg_n && (!r.L_le || !r.R_le))) return BP_ERR_ARG;

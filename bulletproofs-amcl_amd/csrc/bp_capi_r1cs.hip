@@ -36,6 +36,9 @@ struct Temps {
 };
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+// uploads of PROOF data in the verifier: a point off the curve / a non-canonical encoding is a failed verification
+// (the reference fails while deserialising), not a caller error
+#define RCV(expr) do { int rc_ = (expr); if (rc_) return rc_ == BP_ERR_ARG ? BP_ERR_VERIFY : rc_; } while (0)
 
 inline size_t padded_len(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 inline size_t lg_of(size_t p) { size_t l = 0; while (((size_t)1 << l) < p) l++; return l; }
@@ -304,7 +307,7 @@ struct R1cs {
         memcpy(hp.data() + (11 + m) * pb, g_le, pb);
         memcpy(hp.data() + (12 + m) * pb, h_le, pb);
         bp_g1vec* d_hp = nullptr;
-        RC(bp_g1vec_upload(ctx, hp.data(), head, BP_FMT_LE, &d_hp));
+        RCV(bp_g1vec_upload(ctx, hp.data(), head, BP_FMT_LE, &d_hp));
         T.keep(d_hp);
         hipStream_t s = ctx->stream;
         HIPCHK(hipMemcpyAsync(pts->d, d_hp->d, head * row, hipMemcpyDeviceToDevice, s));
@@ -315,7 +318,7 @@ struct R1cs {
             memcpy(lr.data(), Lp, lg * pb);
             memcpy(lr.data() + lg * pb, Rp, lg * pb);
             bp_g1vec* d_lr = nullptr;
-            RC(bp_g1vec_upload(ctx, lr.data(), 2 * lg, BP_FMT_LE, &d_lr));
+            RCV(bp_g1vec_upload(ctx, lr.data(), 2 * lg, BP_FMT_LE, &d_lr));
             T.keep(d_lr);
             HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (head + 2 * pn) * row, d_lr->d, 2 * lg * row, hipMemcpyDeviceToDevice, s));
         }
@@ -352,11 +355,19 @@ int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const
 
 int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                    const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, size_t proof_len, const uint8_t* r_le32) {
-    if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || (m && !V_le) || !proof || !r_le32 || n == 0) return BP_ERR_ARG;
+    if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || (m && !V_le) || !proof || n == 0) return BP_ERR_ARG;
     if (proof_len != bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_VERIFY;
     size_t pn = 1;
     while (pn < n) pn <<= 1;
     if (G->n < pn || H->n < pn) return BP_ERR_LENGTH;                      // verifier.rs:296-298
+    // The verifier's weight r (verifier.rs:392, FieldElement::random()): drawn here unless the caller supplies one (tests).
+    // r = 0 would drop the t(x) / constraint check from the combined MSM, so it is refused, as is a non-canonical value.
+    uint8_t rbuf[32];
+    if (!r_le32) {
+        int rcr = bp_fr_random(ctx->curve, rbuf, 1);
+        if (rcr) return rcr;
+        r_le32 = rbuf;
+    } else if (!bp_fr_is_canonical_nonzero(ctx->curve, r_le32)) return BP_ERR_ARG;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
     return R1cs<Bn254>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);

@@ -1,9 +1,16 @@
 // bp_internal.hpp -- private declarations shared by the translation units of libbpmsm.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "../../include/bpmsm.h"
 #include "bp_kernels.cuh"
@@ -32,6 +39,103 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Per-context caching allocator for the vectors and temporaries of the proof path.  hipMalloc costs tens of microseconds and
+// hipFree synchronises the whole device; a proof creates dozens of short-lived vectors (bp_frvec_alloc / bp_g1vec_alloc, the
+// IPP state, the verifier's term arrays), which at n = 64 cost more than the kernels.  Blocks are recycled by size class and
+// never returned to the driver before the pool dies.  Safe because every use of a context's memory is ordered on the context's
+// stream: a block handed out again is only touched by work queued after the work that last used it (bp_ctx_set_stream
+// synchronises when the stream changes).  The pool is reference-counted: handles may outlive their context.
+struct DevPool {
+    int device = 0;
+    std::mutex mu;
+    std::atomic<long> refs{1};
+    std::map<size_t, std::vector<void*>> free_;   // capacity -> blocks
+    size_t cached_bytes = 0;
+    static size_t size_class(size_t bytes) {
+        if (bytes < 256) return 256;
+        if (bytes <= ((size_t)1 << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+        return (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);      // large vectors: whole MiB, exact reuse
+    }
+    void* get(size_t bytes, size_t* cap) {
+        const size_t c = size_class(bytes);
+        *cap = c;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_.find(c);
+            if (it != free_.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); cached_bytes -= c; refs++; return p; }
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, c) != hipSuccess) {
+            trim();                                                               // give cached blocks back and retry once
+            if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+        }
+        refs++;
+        return p;
+    }
+    void put(void* p, size_t cap) {
+        if (!p) return;
+        bool dead;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_[cap].push_back(p);
+            cached_bytes += cap;
+            dead = --refs == 0;
+        }
+        if (dead) destroy();
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lk(mu);
+        (void)hipSetDevice(device);
+        for (auto& kv : free_) for (void* p : kv.second) (void)hipFree(p);
+        free_.clear();
+        cached_bytes = 0;
+    }
+    void release() { if (--refs == 0) destroy(); }     // the context's own reference
+    void destroy() { trim(); delete this; }
+};
+
+// One helper thread per context for host work that can run beside the calling thread (the second serial tail of a paired
+// MSM): started on first use, parked on a condition variable in between (spawning a std::thread per pair cost ~40 us each).
+struct HostWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, quit = false, started = false;
+    bool submit(std::function<void()> f) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            try { th = std::thread([this] { run(); }); } catch (...) { return false; }
+            started = true;
+        }
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+        return true;
+    }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return done; }); }
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return has_job || quit; });
+            if (quit) return;
+            std::function<void()> f = std::move(job);
+            has_job = false;
+            lk.unlock();
+            f();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    ~HostWorker() {
+        if (!started) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+        th.join();
+    }
+};
+
 struct bp_ctx {
     int curve = 0;
     int device = 0;
@@ -53,16 +157,37 @@ struct bp_ctx {
     bool ev_ready = false;
     float last_ms[8] = {};
     int last_ms_n = 0;
+    DevPool* pool = nullptr;            // vectors and temporaries (see DevPool)
+    HostWorker worker;
+    DevBuf flags;                       // 64 B of device error flags (point / scalar validation)
+    // geometry of the MSM queued by bp_msm_g1_begin (consumed by _end; bp_ctx_set_window_bits in between cannot disturb it)
+    int pending_W = 0;
+    uint8_t pending_cw[256] = {};
 };
 
-// Handles remember their device ordinal so that they can be freed after their context is gone
-// (hipFree synchronises with outstanding work on the device by itself).
+// RAII block from a context's pool (temporaries inside one call)
+struct PoolBlock {
+    DevPool* pool = nullptr;
+    void* p = nullptr;
+    size_t cap = 0;
+    PoolBlock() = default;
+    PoolBlock(const PoolBlock&) = delete;
+    PoolBlock& operator=(const PoolBlock&) = delete;
+    bool alloc(bp_ctx* ctx, size_t bytes) { release(); pool = ctx->pool; p = pool->get(bytes ? bytes : 1, &cap); return p != nullptr; }
+    void release() { if (p) pool->put(p, cap); p = nullptr; }
+    ~PoolBlock() { release(); }
+};
+
+// Handles keep a reference on their context's pool, so they can be freed after the context is gone (the block is then
+// released to the driver together with the pool).
 struct bp_g1vec {
     bp_ctx* ctx;
     void* d;
     size_t n;
     bool owned;
     int device;
+    DevPool* pool = nullptr;   // owned blocks come from (and return to) this pool
+    size_t cap = 0;
 };
 struct bp_frvec {
     bp_ctx* ctx;
@@ -70,6 +195,8 @@ struct bp_frvec {
     size_t n;
     bool owned;
     int device;
+    DevPool* pool = nullptr;
+    size_t cap = 0;
 };
 
 static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }

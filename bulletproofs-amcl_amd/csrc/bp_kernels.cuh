@@ -551,9 +551,12 @@ __global__ void __launch_bounds__(64) k_tail_fold(const XyzzPacked<C>* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- conversions
-// canonical LE words (x || y per point) <-> resident packed Montgomery affine
+// canonical LE words (x || y per point) <-> resident packed Montgomery affine.
+// err != nullptr: VALIDATING form used for every point that arrives from outside (amcl's G1::from_bytes checks the curve
+// equation; the a = 0 formulas here are only complete ON the curve): a coordinate >= p (non-canonical encoding) or a point off
+// y^2 = x^3 + b sets bit 0 of *err and is stored as the identity, so that nothing downstream computes with it.
 template <class C>
-__global__ void __launch_bounds__(kBlock) k_points_to_resident(const uint32_t* __restrict__ raw, size_t n, AffPacked<C>* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_points_to_resident(const uint32_t* __restrict__ raw, size_t n, AffPacked<C>* __restrict__ out, uint32_t* __restrict__ err) {
     using Fp = typename C::Fp;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -563,7 +566,20 @@ __global__ void __launch_bounds__(kBlock) k_points_to_resident(const uint32_t* _
     Aff<C> a;
     a.x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
     a.y = fe_to_mont<Fp>(fe_unpack_words<Fp>(yw));
+    if (err) {
+        bool ok = words_lt_mod<Fp>(xw) && words_lt_mod<Fp>(yw) && aff_on_curve(a);
+        if (!ok) { atomicOr(err, 1u); a.x = fe_zero<Fp>(); a.y = fe_zero<Fp>(); }
+    }
     out[i] = aff_pack(a);
+}
+
+// scalars must be canonical (< r): the signed-digit recoding adds a bias and assumes k < 2^fr_bits
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_check_scalars(const ScalarWords* __restrict__ k, size_t n, uint32_t* __restrict__ err) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ScalarWords s = k[i];
+    if (!words_lt_mod<typename C::Fr>(s.w)) atomicOr(err, 2u);
 }
 
 template <class C>

@@ -22,11 +22,23 @@ def all_gather_records(mine, world):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return mine
-    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
     if dist.get_backend() == "nccl":
+        out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(out, mine)
-    else:
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        out = torch.cat(parts)
+    else:                                     # gloo: CPU tests and one-device rehearsals; records travel through host memory
+        host = mine.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        out = torch.cat(parts).to(mine.device)
     return out
+
+
+def largest_shard(n_total, world):
+    return -(-n_total // world)
+
+
+def common_window_bits(bp, curve, n_total, world):
+    """The window width every rank must fix (Context.set_window_bits) before Context-level two-stage calls when shard sizes may
+    differ: the width the library picks for the LARGEST shard.  Record blocks carry their geometry and bp_msm_g1_finish
+    refuses sets that disagree, so forgetting this fails loudly instead of mis-weighting windows."""
+    return bp.msm_geometry(curve, largest_shard(n_total, world))[0]

@@ -79,9 +79,15 @@ int bp_ctx_synchronize(bp_ctx* ctx);
 int bp_ctx_set_device_tail(bp_ctx* ctx, int on);
 /* Pippenger window width in bits (2..16) for subsequent MSMs; 0 = choose from n (default). */
 int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
+/* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
+ * of a small proof; blocks are recycled in stream order).  bp_ctx_trim returns the cached blocks to the driver. */
+int bp_ctx_trim(bp_ctx* ctx);
 
 /* ---- G1Vector --------------------------------------------------------------------------------------------- */
-/* G1Vector::from(Vec<G1>) : host bytes -> HBM (converted to packed Montgomery affine on the device). */
+/* G1Vector::from(Vec<G1>) : host bytes -> HBM (converted to packed Montgomery affine on the device).
+ * Every point is VALIDATED as amcl's G1::from_bytes does: BP_ERR_ARG if a coordinate is not canonical (>= p) or the point
+ * is not on y^2 = x^3 + b (the all-zero identity encoding is accepted).  The verifiers upload proof points through the same
+ * check and report BP_ERR_VERIFY.  bp_g1vec_wrap_device is the unchecked door for memory the caller already trusts. */
 int bp_g1vec_upload(bp_ctx* ctx, const uint8_t* points, size_t n, int fmt, bp_g1vec** out);
 /* G1Vector::with_capacity / new(n): n identity points. */
 int bp_g1vec_alloc(bp_ctx* ctx, size_t n, bp_g1vec** out);
@@ -113,6 +119,8 @@ int bp_get_generators(bp_ctx* ctx, const uint8_t* prefix, size_t prefix_len, uin
 int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1vec** out);
 
 /* ---- FieldElementVector ------------------------------------------------------------------------------------- */
+/* Scalars must be canonical (< r): BP_ERR_ARG otherwise (the window recoding of the MSM assumes it; a value >= r would wrap
+ * silently).  bp_frvec_wrap_device is unchecked. */
 int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec** out);
 int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out); /* zeros */
 int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, uint8_t* out_le32);
@@ -152,7 +160,11 @@ int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1
  * caller-owned HBM buffer.  The caller all-gathers the N ranks' records over RCCL (point addition is not an RCCL
  * reduction op; N*W*192 B is latency-bound).  Stage 2 (bp_msm_g1_finish): one D2H copy of `sets`
  * record sets, per-window sum, the serial 2^(c w) fold and the affine normalisation, giving BP_FMT_LE bytes.
- * All ranks must use the same n_per_set (or the same bp_ctx_set_window_bits) so that window geometry agrees.
+ * A record block is W window records followed by ONE header record naming the geometry (c, W, widths) that produced it;
+ * bp_msm_window_records counts both.  bp_msm_g1_finish recomputes the geometry from n_per_set (and the context's
+ * bp_ctx_set_window_bits) and returns BP_ERR_ARG if any set's header disagrees -- ranks whose shard sizes differ (index
+ * ranges differ by one) must therefore fix a common width first: bp_ctx_set_window_bits(ctx, c) with the c of
+ * bp_msm_geometry(curve, largest shard, 0, ...), and pass that shard size as n_per_set.
  * bp_msm_g1_windows returns after the records are complete in device_out (it synchronises the context's stream), so they
  * can be handed to a collective on any other stream; the caller must in turn complete the gather before bp_msm_g1_finish. */
 size_t bp_msm_window_records(bp_ctx* ctx, size_t n);
@@ -160,6 +172,23 @@ size_t bp_msm_record_bytes(int curve_id);
 int bp_msm_g1_windows(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n,
                       void* device_out);
 int bp_msm_g1_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le);
+/* Stage 2 on HOST memory, no GPU needed (an aggregator that only receives record blocks): same validation and fold.
+ * window_bits: 0 = the width chosen from n_per_set, else the common width the ranks fixed. */
+int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, size_t n_per_set, int window_bits, uint8_t* out_le);
+/* The window geometry an MSM of n terms uses (host arithmetic): width c, W windows, per-window widths cw[W] and bit offsets
+ * off[W], and the recoding bias (window w of k + bias, minus 2^(cw-1) - 1, is the signed digit of window w).  Any output
+ * pointer may be NULL. */
+int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32);
+/* Record-block helpers for hosts that build or check blocks themselves (tests, aggregators): an affine point as a window
+ * record, and the header record of the geometry above.  Host arithmetic. */
+int bp_msm_record_from_affine(int curve_id, const uint8_t* point_le, void* record_out);
+int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_out);
+/* The whole sharded MSM from ONE host thread without torch / RCCL (a Rust caller of G1Vector::multi_scalar_mul_var_time,
+ * src/ipp.rs:251-253, has neither): shard i = (points[i], scalars[i]) is resident with ctxs[i] -- contexts on different
+ * devices of the node, or several on one device.  All shards run concurrently with one common window width; each device
+ * copies its W window sums (W x 192 B) to pinned host memory and the caller's thread folds the n_shards sets.  That gather
+ * IS the "reduce" of the partial sums: n_shards x 3 KiB, latency-bound; point addition is not an RCCL op. */
+int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp_frvec* const* scalars, size_t n_shards, uint8_t* out_le);
 
 /* Timing of the last bp_msm_* call on this context, measured with HIP events on the context's stream.
  * ms[0] = whole device pipeline, ms[1..] = per stage (digits+count, scan, scatter, tasks, accumulate, reduce); returns the
@@ -186,6 +215,11 @@ int bp_vecpoly1_inner_product(bp_ctx* ctx, const bp_frvec* const l[2], const bp_
 int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uint8_t* x_le32, bp_frvec** out);
 /* FieldElement::inverse (src/ipp.rs:113,179); host arithmetic, no GPU needed; inverse of 0 is 0. */
 int bp_fr_inverse(int curve_id, const uint8_t* in_le32, uint8_t* out_le32);
+/* FieldElement::random() (src/r1cs/verifier.rs:392; the provers' blindings, prover.rs:337-341): n uniform non-zero scalars
+ * from the operating system's generator (getrandom).  Host only. */
+int bp_fr_random(int curve_id, uint8_t* out_le32, size_t n);
+/* 1 if 0 < x < r (canonical, non-zero), else 0. */
+int bp_fr_is_canonical_nonzero(int curve_id, const uint8_t* x_le32);
 
 /* ---- transcript: merlin::Transcript + TranscriptProtocol (src/transcript.rs:12-61); host only -------------------- */
 typedef struct bp_transcript bp_transcript;
@@ -240,8 +274,9 @@ int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_fac
  * together iff  sum_j w_j * (G^(a_j s_j) H^(b_j / s_j) Q_j^(a_j b_j) - P_j - sum_k (u_jk^2 L_jk + u_jk^-2 R_jk)) == O,
  * i.e. ONE MSM of 2n + m (2 lg n + 2) terms instead of m MSMs of 2n + 2 lg n + 1 -- the random-linear-combination
  * argument the reference's verifier already uses inside one proof (src/r1cs/verifier.rs:392) applied across proofs.
- * weights_le32: m canonical scalars chosen by the caller AFTER the proofs are fixed, from a source the provers cannot
- * predict (128 random bits each are enough); a forged proof then passes with probability ~ 1/r.  BP_ERR_VERIFY does
+ * weights_le32: NULL (the library draws m fresh scalars with bp_fr_random), or m canonical NON-ZERO scalars chosen by the
+ * caller AFTER the proofs are fixed, from a source the provers cannot predict (BP_ERR_ARG for a zero / non-canonical
+ * weight); a forged proof then passes with probability ~ 1/r.  BP_ERR_VERIFY does
  * not say which proof failed: fall back to bp_ipp_verify per proof.  Each transcript is advanced exactly as by
  * bp_ipp_verify. */
 typedef struct bp_ipp_proof_ref {
@@ -282,7 +317,10 @@ int bp_r1cs_flattened_constraints(bp_ctx* ctx, const bp_r1cs_plan* plan, const u
  * prove: a_L, a_R, a_O, s_L, s_R of length n (gates), v_blinding of length m (may be NULL when m = 0); blindings_le32 = eight
  * scalars i, o, s, t1, t3, t4, t5, t6 (the reference draws them from its RNG, prover.rs:337-341,490-494).  G, H need at
  * least padded-n points (BP_ERR_LENGTH = R1CSError::InvalidGeneratorsLength).
- * verify: r_le32 = the verifier's random weight (verifier.rs:392); BP_ERR_VERIFY if the combined MSM is not the identity. */
+ * verify: r_le32 = the verifier's random weight (verifier.rs:392): pass NULL and the library draws it (bp_fr_random), as the
+ * reference does; an explicit value is for reproducible tests and must be canonical and non-zero (BP_ERR_ARG: r = 0 would
+ * drop the t(x) / constraint check from the combined MSM).  BP_ERR_VERIFY if the combined MSM is not the identity or a proof
+ * point is not a point of the curve. */
 size_t bp_r1cs_proof_bytes(int curve_id, size_t n);
 int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                   const uint8_t* h_le, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O, const bp_frvec* v_blinding, const bp_frvec* s_L,

@@ -29,3 +29,30 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["matches_gpu"] is True and "sample" in c
     assert abs(d["value"] - (1 << 14) * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+def test_bench_self_launches_n_ranks_and_strong_scaling():
+    """`python bench.py --gpus 2 --strong` with no RANK in the environment starts the two ranks itself.  On this
+    one-GPU box both ranks use GPU 0 and exchange records over gloo (--rehearse-one-device); the code path -- self-launch, index
+    range split of a fixed total, record blocks with geometry headers, gather, finish over 2 sets, oracle check -- is the one
+    the driver's N = 2, 4, 8 runs take with RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong", "--lg-n", "15", "--steps", "2", "--warmup", "1",
+                        "--rehearse-one-device"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rehearsal"] is True and d["verified"] is True
+    assert d["config"]["n_total"] == 1 << 15 and d["config"]["n_per_gpu"] == 1 << 14
+    # weak scaling keeps the per-GPU size
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lg-n", "14", "--steps", "2", "--warmup", "1",
+                        "--rehearse-one-device"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["n_total"] == 1 << 15 and d["verified"] is True
+    # a mismatch between --gpus and an existing process group is an error, not a silent 1-GPU line
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--lg-n", "12", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                                                                              MASTER_PORT="29611"))
+    assert p.returncode == 2 and not p.stdout.strip()

@@ -1,6 +1,8 @@
-"""CPU, world_size 2, gloo: the N > 1 plumbing (index-range shards, one all_gather of per-rank records, finish).
-The per-rank device stage is played by the oracle here (there is no GPU); what is under test is the sharding and
-the exchange step that bench.py --gpus N uses with RCCL."""
+"""CPU, world_size 2, gloo: the N > 1 path of the sharded MSM without a GPU.  Each rank plays the DEVICE stage with the oracle
+(the W window sums of its index range, recoded with the library's own window table, bp_msm_geometry) and packs them as the
+library's record block; the exchange step (sharding.all_gather_records, RCCL on GPUs / gloo here) and stage 2 -- header
+validation + the host fold, bp_msm_g1_finish_host, the same code bp_msm_g1_finish runs after its D2H copy -- are the
+PRODUCT's.  Ragged shards (501 + 500) with the common window width of sharding.common_window_bits."""
 import os
 import subprocess
 import sys
@@ -22,17 +24,35 @@ from bulletproofs_amcl_amd import sharding
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 curve, n = 0, 1001                                   # ragged: 501 + 500
+r = O.group_order(curve)
 ks = O.random_scalars(curve, 5, n); ss = O.random_scalars(curve, 6, n)
 pts = O.fixed_base_batch(curve, ks, n, 2)
 lo, hi = sharding.shard_range(n, world, rank)
-part = O.msm(curve, pts[lo * 96:hi * 96], ss[lo * 32:hi * 32], hi - lo, algo=O.PIPPENGER)
-mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+c = sharding.common_window_bits(bp, curve, n, world)
+nmax = sharding.largest_shard(n, world)
+_, cw, off, bias = bp.msm_geometry(curve, nmax, c)
+# device stage, played by the oracle: S_w = sum_i digit_w(k_i) P_i over this rank's index range
+block = b""
+for w in range(len(cw)):
+    digs = b""
+    for i in range(lo, hi):
+        k = int.from_bytes(ss[32 * i:32 * i + 32], "little") + bias
+        d = ((k >> off[w]) & ((1 << cw[w]) - 1)) - ((1 << (cw[w] - 1)) - 1)
+        digs += (d %% r).to_bytes(32, "little")
+    S = O.msm(curve, pts[lo * 96:hi * 96], digs, hi - lo, algo=O.PIPPENGER)
+    block += bp.msm_record_from_affine(curve, S)
+block += bp.msm_record_header(curve, nmax, c)
+mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
 allrec = sharding.all_gather_records(mine, world)
-acc = bytes(96)
-for r in range(world):
-    acc = O.g1_add(curve, acc, bytes(allrec[r * 96:(r + 1) * 96].tolist()))
+got = bp.msm_finish_host(curve, bytes(allrec.tolist()), world, nmax, c)
 want = O.msm(curve, pts, ss, n, algo=O.PIPPENGER)
-assert acc == want, "sharded sum differs"
+assert got == want, "sharded sum differs"
+# a rank that picked another width is refused, not mis-folded
+bad = bytearray(bytes(allrec.tolist())); bad[len(block) - 192 + 4] ^= 1
+try:
+    bp.msm_finish_host(curve, bytes(bad), world, nmax, c); raise SystemExit("geometry mismatch was not detected")
+except bp.ArgError:
+    pass
 t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == world
 dist.barrier(); dist.destroy_process_group()
 sys.stdout.write("rank-%%d-ok\n" %% rank); sys.stdout.flush()
