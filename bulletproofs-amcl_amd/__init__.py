@@ -106,6 +106,12 @@ SYMBOLS = {
     "bp_msm_record_header": (_I, [_I, _SZ, _I, _P]),
     "bp_msm_g1_multi": (_I, [_PP, _PP, _PP, _SZ, _U8P]),
     "bp_ctx_trim": (_I, [_P]),
+    "bp_g1_compressed_bytes": (_SZ, [_I]),
+    "bp_g1vec_compress": (_I, [_P, _P, _SZ, _SZ, _U8P]),
+    "bp_g1vec_decompress": (_I, [_P, _U8P, _SZ, _PP]),
+    "bp_r1cs_proof_compressed_bytes": (_SZ, [_I, _SZ]),
+    "bp_r1cs_proof_compress": (_I, [_P, _SZ, _U8P, _SZ, _U8P, _SZ]),
+    "bp_r1cs_proof_decompress": (_I, [_P, _SZ, _U8P, _SZ, _U8P, _SZ]),
     "bp_fr_random": (_I, [_I, _U8P, _SZ]),
     "bp_fr_is_canonical_nonzero": (_I, [_I, _U8P]),
     "bp_msm_last_timing": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
@@ -292,6 +298,19 @@ class G1Vector:
         h = ctypes.c_void_p()
         _check(lib().bp_g1vec_commit_pairs(ctx.h, bytes(g_le), bytes(h_le), k1.h, k2.h, ctypes.byref(h)), "bp_g1vec_commit_pairs")
         return cls(ctx, h)
+
+    @classmethod
+    def from_compressed(cls, ctx, data, n):
+        """tag || X per point (bp_g1vec_decompress); ArgError if a point does not decode"""
+        h = ctypes.c_void_p()
+        _check(lib().bp_g1vec_decompress(ctx.h, bytes(data), n, ctypes.byref(h)), "bp_g1vec_decompress")
+        return cls(ctx, h)
+
+    def to_compressed(self, offset=0, n=None):
+        n = len(self) - offset if n is None else n
+        buf = ctypes.create_string_buffer(max(1, n * lib().bp_g1_compressed_bytes(self.ctx.curve)))
+        _check(lib().bp_g1vec_compress(self.ctx.h, self.h, offset, n, buf), "bp_g1vec_compress")
+        return buf.raw[:n * lib().bp_g1_compressed_bytes(self.ctx.curve)]
 
     def scaled_by(self, scalars):
         """[k_i * P_i]"""
@@ -792,6 +811,20 @@ def r1cs_verify(ctx, transcript, plan, G, H, g_le, h_le, V_le, n, proof, r_le32=
     m = len(V_le) // ctx.point_bytes
     _check(lib().bp_r1cs_verify(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), bytes(V_le) or None, n, m, bytes(proof), len(proof),
                                 bytes(r_le32) if r_le32 is not None else None), "bp_r1cs_verify")
+
+
+def r1cs_proof_compress(ctx, n, proof):
+    size = lib().bp_r1cs_proof_compressed_bytes(ctx.curve, n)
+    out = ctypes.create_string_buffer(size)
+    _check(lib().bp_r1cs_proof_compress(ctx.h, n, bytes(proof), len(proof), out, size), "bp_r1cs_proof_compress")
+    return out.raw
+
+
+def r1cs_proof_decompress(ctx, n, data):
+    size = lib().bp_r1cs_proof_bytes(ctx.curve, n)
+    out = ctypes.create_string_buffer(size)
+    _check(lib().bp_r1cs_proof_decompress(ctx.h, n, bytes(data), len(data), out, size), "bp_r1cs_proof_decompress")
+    return out.raw
 
 
 def r1cs_prover_polys(ctx, a_L, a_R, a_O, s_L, s_R, wL, wR, wO, y_le32):

@@ -66,9 +66,111 @@ int hash_common(bp_ctx* ctx, const uint8_t* bytes, size_t nbytes, const uint64_t
     return BP_OK;
 }
 
+template <class C>
+int compress_impl(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, uint8_t* out) {
+    const size_t per = C::MODBYTES + 1;
+    PoolBlock stage;
+    if (!stage.alloc(ctx, n * per)) return BP_ERR_DEVICE;
+    hipLaunchKernelGGL(k_g1_compress<C>, dim3((unsigned)((n + kHashBlock - 1) / kHashBlock)), dim3(kHashBlock), 0, ctx->stream,
+                       (const AffPacked<C>*)v->d + offset, n, (uint8_t*)stage.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, stage.p, n * per, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+
+template <class C>
+int decompress_impl(bp_ctx* ctx, const uint8_t* in, size_t n, bp_g1vec* out) {
+    const size_t per = C::MODBYTES + 1;
+    PoolBlock stage;
+    if (!stage.alloc(ctx, n * per)) return BP_ERR_DEVICE;
+    int rc;
+    if ((rc = ctx->flags.reserve(64))) return rc;
+    uint32_t* flag = (uint32_t*)ctx->flags.p;
+    uint32_t host_flag = 0;
+    HIPCHK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+    HIPCHK(hipMemcpyAsync(stage.p, in, n * per, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_g1_decompress<C>, dim3((unsigned)((n + kHashBlock - 1) / kHashBlock)), dim3(kHashBlock), 0, ctx->stream, (const uint8_t*)stage.p, n,
+                       sqrt_exponent<C>(), (AffPacked<C>*)out->d, flag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return host_flag ? BP_ERR_ARG : BP_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t bp_g1_compressed_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? Bls381::MODBYTES + 1 : curve_id == BP_CURVE_BN254 ? Bn254::MODBYTES + 1 : 0; }
+
+int bp_g1vec_compress(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, uint8_t* out) {
+    if (!ctx || !v || (!out && n)) return BP_ERR_ARG;
+    if (offset > v->n || n > v->n - offset) return BP_ERR_LENGTH;
+    if (n == 0) return BP_OK;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    return ctx->curve == BP_CURVE_BLS12_381 ? compress_impl<Bls381>(ctx, v, offset, n, out) : compress_impl<Bn254>(ctx, v, offset, n, out);
+}
+
+int bp_g1vec_decompress(bp_ctx* ctx, const uint8_t* in, size_t n, bp_g1vec** out) {
+    if (!ctx || !out || (!in && n)) return BP_ERR_ARG;
+    *out = nullptr;
+    int rc = bp_g1vec_alloc(ctx, n, out);
+    if (rc || n == 0) return rc;
+    rc = ctx->curve == BP_CURVE_BLS12_381 ? decompress_impl<Bls381>(ctx, in, n, *out) : decompress_impl<Bn254>(ctx, in, n, *out);
+    if (rc) { bp_g1vec_free(*out); *out = nullptr; }
+    return rc;
+}
+
+// R1CS proof <-> its compressed wire form: every point of the layout of bp_r1cs_prove as 1 + MODBYTES bytes, the five scalars
+// unchanged.  11 + 2 lg points: 49 instead of 96 bytes each for BLS12-381 (4 288 -> 2 549 bytes at 2^16 gates).
+static size_t r1cs_points(size_t n) { size_t p = 1, lg = 0; while (p < n) { p <<= 1; lg++; } return 11 + 2 * lg; }
+
+size_t bp_r1cs_proof_compressed_bytes(int curve_id, size_t n) {
+    if (!curve_ok(curve_id) || n == 0) return 0;
+    return r1cs_points(n) * bp_g1_compressed_bytes(curve_id) + 5 * 32;
+}
+
+int bp_r1cs_proof_compress(bp_ctx* ctx, size_t n, const uint8_t* proof, size_t proof_len, uint8_t* out, size_t out_cap) {
+    if (!ctx || !proof || !out || n == 0) return BP_ERR_ARG;
+    const size_t pb = 2 * (size_t)fp_bytes_of(ctx->curve), np = r1cs_points(n), cb = bp_g1_compressed_bytes(ctx->curve);
+    if (proof_len != np * pb + 5 * 32 || out_cap < np * cb + 5 * 32) return BP_ERR_LENGTH;
+    // layout: 11 points | 3 scalars | 2 lg points | 2 scalars  ->  gather the points, compress, interleave again
+    std::vector<uint8_t> pts(np * pb), comp(np * cb);
+    memcpy(pts.data(), proof, 11 * pb);
+    memcpy(pts.data() + 11 * pb, proof + 11 * pb + 96, (np - 11) * pb);
+    bp_g1vec* v = nullptr;
+    int rc = bp_g1vec_upload(ctx, pts.data(), np, BP_FMT_LE, &v);
+    if (rc) return rc;
+    rc = bp_g1vec_compress(ctx, v, 0, np, comp.data());
+    bp_g1vec_free(v);
+    if (rc) return rc;
+    memcpy(out, comp.data(), 11 * cb);
+    memcpy(out + 11 * cb, proof + 11 * pb, 96);
+    memcpy(out + 11 * cb + 96, comp.data() + 11 * cb, (np - 11) * cb);
+    memcpy(out + np * cb + 96, proof + np * pb + 96, 64);
+    return BP_OK;
+}
+
+int bp_r1cs_proof_decompress(bp_ctx* ctx, size_t n, const uint8_t* in, size_t in_len, uint8_t* proof_out, size_t proof_cap) {
+    if (!ctx || !in || !proof_out || n == 0) return BP_ERR_ARG;
+    const size_t pb = 2 * (size_t)fp_bytes_of(ctx->curve), np = r1cs_points(n), cb = bp_g1_compressed_bytes(ctx->curve);
+    if (in_len != np * cb + 5 * 32 || proof_cap < np * pb + 5 * 32) return BP_ERR_LENGTH;
+    std::vector<uint8_t> comp(np * cb), pts(np * pb);
+    memcpy(comp.data(), in, 11 * cb);
+    memcpy(comp.data() + 11 * cb, in + 11 * cb + 96, (np - 11) * cb);
+    bp_g1vec* v = nullptr;
+    int rc = bp_g1vec_decompress(ctx, comp.data(), np, &v);
+    if (rc) return rc == BP_ERR_ARG ? BP_ERR_VERIFY : rc;      // a proof that does not decode is a proof that does not verify
+    rc = bp_g1vec_download(ctx, v, 0, np, BP_FMT_LE, pts.data());
+    bp_g1vec_free(v);
+    if (rc) return rc;
+    memcpy(proof_out, pts.data(), 11 * pb);
+    memcpy(proof_out + 11 * pb, in + 11 * cb, 96);
+    memcpy(proof_out + 11 * pb + 96, pts.data() + 11 * pb, (np - 11) * pb);
+    memcpy(proof_out + np * pb + 96, in + np * cb + 96, 64);
+    return BP_OK;
+}
 
 int bp_g1vec_from_msg_hash(bp_ctx* ctx, const uint8_t* msgs, const uint64_t* offsets, size_t n, bp_g1vec** out) {
     if (!ctx || !out || (n && !offsets)) return BP_ERR_ARG;

@@ -214,4 +214,65 @@ __global__ void __launch_bounds__(kHashBlock, 2) k_clear_cofactor(size_t n, Sqrt
     }
 }
 
+// ---------------------------------------------------------------------------------------------- compressed points
+// the proof structs derive serde (src/ipp.rs:13, src/r1cs/proof.rs:24) and amcl can write a point as one
+// coordinate and a sign.  Wire form of THIS build (amcl's own compressed bytes cannot be checked here, so the format is not
+// claimed to be amcl's): 1 + MODBYTES bytes per point,
+//     tag 0x02 (y even) / 0x03 (y odd) || X big-endian          tag 0x00 || zeros = the identity
+// (x = 0 IS an abscissa of y^2 = x^3 + 4 -- y = +-2 -- so the identity needs its own tag.)
+// Decompression: x < p, rhs = x^3 + b a square, y = rhs^((p+1)/4) with the tagged parity; anything else sets bit 0 of *err
+// and yields the identity.  Any other tag, or non-zero bytes behind tag 0, is an error too.
+template <class C>
+__global__ void __launch_bounds__(kHashBlock) k_g1_compress(const AffPacked<C>* __restrict__ pts, size_t n, uint8_t* __restrict__ out) {
+    using Fp = typename C::Fp;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int MB = C::MODBYTES;
+    Aff<C> a = aff_unpack(pts[i]);
+    uint8_t* o = out + i * (size_t)(MB + 1);
+    if (aff_is_inf(a)) { for (int k = 0; k <= MB; k++) o[k] = 0; return; }
+    uint32_t xw[Fp::NW], yw[Fp::NW];
+    fe_pack_words<Fp>(xw, fe_from_mont<Fp>(a.x));
+    fe_pack_words<Fp>(yw, fe_from_mont<Fp>(a.y));
+    o[0] = (uint8_t)(2 + (yw[0] & 1));
+    for (int k = 0; k < MB; k++) o[1 + k] = (uint8_t)(xw[(MB - 1 - k) >> 2] >> (8 * ((MB - 1 - k) & 3)));
+}
+
+template <class C>
+__global__ void __launch_bounds__(kHashBlock, 2) k_g1_decompress(const uint8_t* __restrict__ in, size_t n, SqrtExp e, AffPacked<C>* __restrict__ out,
+                                                                 uint32_t* __restrict__ err) {
+    using Fp = typename C::Fp;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int MB = C::MODBYTES;
+    const uint8_t* p = in + i * (size_t)(MB + 1);
+    uint32_t xw[Fp::NW];
+    for (int k = 0; k < Fp::NW; k++) xw[k] = 0;
+    uint32_t any = 0;
+    for (int k = 0; k < MB; k++) { uint32_t b = p[1 + k]; any |= b; xw[(MB - 1 - k) >> 2] |= b << (8 * ((MB - 1 - k) & 3)); }
+    const uint8_t tag = p[0];
+    Aff<C> a;
+    a.x = fe_zero<Fp>(); a.y = fe_zero<Fp>();
+    bool ok = true;
+    if (tag == 0) ok = any == 0;
+    else if (tag != 2 && tag != 3) ok = false;
+    else if (!words_lt_mod<Fp>(xw)) ok = false;
+    else {
+        Fe<Fp> x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
+        Fe<Fp> braw = fe_zero<Fp>();
+        braw.v[0] = C::B;
+        Fe<Fp> rhs = fe_add(fe_mul(fe_sqr(x), x), fe_to_mont<Fp>(braw));
+        Fe<Fp> s = fe_pow_words<Fp>(rhs, e);
+        if (!fe_eq(fe_sqr(s), rhs) || fe_is_zero(s)) ok = false;      // not a square; y = 0 has even order 2 and is in neither group
+        else {
+            uint32_t sw[Fp::NW];
+            fe_pack_words<Fp>(sw, fe_from_mont<Fp>(s));
+            a.x = x;
+            a.y = ((sw[0] & 1) == (uint32_t)(tag & 1)) ? s : fe_neg(s);
+        }
+    }
+    if (!ok) { atomicOr(err, 1u); a.x = fe_zero<Fp>(); a.y = fe_zero<Fp>(); }
+    out[i] = aff_pack(a);
+}
+
 }  // namespace bp

@@ -363,10 +363,41 @@ def gen_r1cs():
     return out
 
 
+def gen_compressed():
+    """bp_g1vec_compress / _decompress (this build's tag || X form, pyref.g1_compress): multiples of the generator with both y
+    parities, the identity, hashed points; and encodings that must be refused."""
+    out = {}
+    for c in (R.BLS12_381, R.BN254):
+        rng = R.SplitMix64(SEED + 700 + c.curve_id)
+        pts = [None, c.g, c.neg(c.g), c.mul(2, c.g), c.mul(c.r - 1, c.g)] + [c.mul(rng.scalar(c), c.g) for _ in range(8)]
+        pts += [R.g1_from_msg_hash(c, m) for m in (b"g", b"h", b"Q")] + [None]
+        cases = []
+        for P in pts:
+            enc = R.g1_compress(c, P)
+            assert R.g1_decompress(c, enc) == P
+            cases.append({"point": pt_le(c, P), "compressed": h(enc)})
+        assert {bytes.fromhex(x["compressed"])[0] for x in cases} == {0, 2, 3}
+        mb = c.modbytes
+        x_off = next(x for x in range(1, 200) if pow((x ** 3 + c.b) % c.p, (c.p - 1) // 2, c.p) != 1)      # not an abscissa
+        invalid = [{"why": "x is not an abscissa of the curve", "bytes": h(bytes([2]) + x_off.to_bytes(mb, "big"))},
+                   {"why": "x >= p", "bytes": h(bytes([3]) + (c.p + 1 if (c.p + 1).bit_length() <= 8 * mb else c.p).to_bytes(mb, "big"))},
+                   {"why": "x = p", "bytes": h(bytes([2]) + c.p.to_bytes(mb, "big"))},
+                   {"why": "unknown tag", "bytes": h(bytes([4]) + c.g[0].to_bytes(mb, "big"))},
+                   {"why": "identity tag with a non-zero body", "bytes": h(bytes([0]) + (1).to_bytes(mb, "big"))}]
+        for bad in invalid:
+            try:
+                R.g1_decompress(c, bytes.fromhex(bad["bytes"]))
+                raise AssertionError("accepted: " + bad["why"])
+            except ValueError:
+                pass
+        out[c.name] = {"cases": cases, "invalid": invalid}
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("curves", gen_curves), ("field", gen_field), ("g1", gen_g1), ("merlin", gen_merlin),
-                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1), ("r1cs", gen_r1cs)):
+                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1), ("r1cs", gen_r1cs), ("compressed", gen_compressed)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue                                                   # python3 oracle/gen_golden.py r1cs  -> only that file
         print("generating", name, file=sys.stderr)

@@ -145,6 +145,37 @@ BN254.cofactor = 1
 
 CURVES = {c.name: c for c in (BLS12_381, BN254)}
 
+# --------------------------------------------------------------------------- compressed points
+
+
+def g1_compress(curve, P):
+    """Wire form of THIS build (include/bpmsm.h, bp_g1vec_compress): tag 0x02 / 0x03 (y even / odd) || X big-endian, MODBYTES;
+    identity = tag 0x00 || zeros.  Not claimed to equal amcl's compressed bytes (unverifiable here)."""
+    if P is None:
+        return bytes(curve.modbytes + 1)
+    return bytes([2 + (P[1] & 1)]) + P[0].to_bytes(curve.modbytes, "big")
+
+
+def g1_decompress(curve, data):
+    """-> point / None (identity); raises ValueError for anything that is not the encoding of a curve point."""
+    if len(data) != curve.modbytes + 1:
+        raise ValueError("length")
+    tag, x = data[0], int.from_bytes(data[1:], "big")
+    if tag == 0:
+        if x:
+            raise ValueError("identity with non-zero bytes")
+        return None
+    if tag not in (2, 3) or x >= curve.p:
+        raise ValueError("tag / range")
+    rhs = (x * x * x + curve.b) % curve.p
+    y = pow(rhs, (curve.p + 1) // 4, curve.p)
+    if y * y % curve.p != rhs or y == 0:
+        raise ValueError("not on the curve")
+    if (y & 1) != (tag & 1):
+        y = curve.p - y
+    return (x, y)
+
+
 # --------------------------------------------------------------------------- Keccak / STROBE / Merlin
 
 _RC = [

@@ -134,7 +134,7 @@ def test_unequal_shards_need_a_common_width(bp, name):
     from bulletproofs_amcl_amd import sharding
     cid = bp.CURVE_IDS[name]
     ctx = bp.Context(cid, 0)
-    n, world = 32769 + 32768, 2                              # shards 32769 / 32768 straddle 2^15: c = 14 vs 13 when left to n
+    n, world = 32768 + 32767, 2                              # shards 32768 / 32767 straddle 2^15: c = 14 vs 13 when left to n
     ks, ss = O.random_scalars(cid, 21, n), O.random_scalars(cid, 22, n)
     pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
     sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
@@ -208,3 +208,47 @@ def test_cfg4_split_of_2p22_over_8_shards(bp):
     for c in ctxs:
         c.close()
     main.close()
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_compressed_points(bp, golden, name):
+    """tag || X wire form (this build's; see include/bpmsm.h) against the Python-int restatement in
+    tests/golden/compressed.json -- both y parities, the identity, generator multiples -- and the decode errors."""
+    cid = bp.CURVE_IDS[name]
+    ctx = bp.Context(cid, 0)
+    g = golden("compressed")[name]
+    pts = b"".join(bytes.fromhex(c["point"]) for c in g["cases"])
+    want = b"".join(bytes.fromhex(c["compressed"]) for c in g["cases"])
+    n = len(g["cases"])
+    v = bp.G1Vector.from_bytes(ctx, pts, n)
+    assert v.to_compressed() == want
+    assert bp.G1Vector.from_compressed(ctx, want, n).to_bytes() == pts
+    per = len(want) // n
+    assert {want[i * per] for i in range(n)} == {0, 2, 3}                 # identity and both parities are covered
+    for bad in g["invalid"]:
+        with pytest.raises(bp.ArgError):
+            bp.G1Vector.from_compressed(ctx, want[:per] + bytes.fromhex(bad["bytes"]), 2)
+    # random points at scale, round trip
+    k = 5000
+    big = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, 77, k), k))
+    assert bp.G1Vector.from_compressed(ctx, big.to_compressed(), k).to_bytes() == big.to_bytes()
+    ctx.close()
+
+
+def test_r1cs_proof_compressed_form(bp, golden):
+    from test_oracle_golden import r1cs_case_inputs
+    from test_gpu_r1cs_oracle import start_transcript
+    for name in CURVES:
+        ctx = bp.Context(bp.CURVE_IDS[name], 0)
+        for c in golden("r1cs")[name]:
+            a = r1cs_case_inputs(c)
+            n = c["n"]
+            comp = bp.r1cs_proof_compress(ctx, n, a["proof"])
+            assert len(comp) == bp.lib().bp_r1cs_proof_compressed_bytes(ctx.curve, n) < len(a["proof"])
+            assert bp.r1cs_proof_decompress(ctx, n, comp) == a["proof"]
+            bad = bytearray(comp)
+            bad[0] = 7                                               # unknown tag on A_I1
+            with pytest.raises(bp.VerificationError):
+                bp.r1cs_proof_decompress(ctx, n, bytes(bad))
+        ctx.close()
+    assert bp.lib().bp_r1cs_proof_compressed_bytes(0, 1 << 16) == 2549 and bp.lib().bp_r1cs_proof_bytes(0, 1 << 16) == 4288
