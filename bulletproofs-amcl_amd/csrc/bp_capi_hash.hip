@@ -123,7 +123,7 @@ int bp_g1vec_decompress(bp_ctx* ctx, const uint8_t* in, size_t n, bp_g1vec** out
 }
 
 // R1CS proof <-> its compressed wire form: every point of the layout of bp_r1cs_prove as 1 + MODBYTES bytes, the five scalars
-// unchanged.  11 + 2 lg points: 49 instead of 96 bytes each for BLS12-381 (4 288 -> 2 549 bytes at 2^16 gates).
+// unchanged.  11 + 2 lg points: 49 instead of 96 bytes each for BLS12-381 (4 288 -> 2 267 bytes at 2^16 gates).
 static size_t r1cs_points(size_t n) { size_t p = 1, lg = 0; while (p < n) { p <<= 1; lg++; } return 11 + 2 * lg; }
 
 size_t bp_r1cs_proof_compressed_bytes(int curve_id, size_t n) {

@@ -332,7 +332,7 @@ int bp_r1cs_flattened_constraints(bp_ctx* ctx, const bp_r1cs_plan* plan, const u
  * point is not a point of the curve. */
 size_t bp_r1cs_proof_bytes(int curve_id, size_t n);
 /* The same proof with every point compressed (11 + 2 lg points at 1 + MODBYTES bytes, the five scalars unchanged):
- * 2 549 instead of 4 288 bytes for BLS12-381 at 2^16 gates.  decompress returns BP_ERR_VERIFY for a point that does not decode. */
+ * 2 267 instead of 4 288 bytes for BLS12-381 at 2^16 gates.  decompress returns BP_ERR_VERIFY for a point that does not decode. */
 size_t bp_r1cs_proof_compressed_bytes(int curve_id, size_t n);
 int bp_r1cs_proof_compress(bp_ctx* ctx, size_t n, const uint8_t* proof, size_t proof_len, uint8_t* out, size_t out_cap);
 int bp_r1cs_proof_decompress(bp_ctx* ctx, size_t n, const uint8_t* in, size_t in_len, uint8_t* proof_out, size_t proof_cap);

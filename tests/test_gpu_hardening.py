@@ -251,4 +251,4 @@ def test_r1cs_proof_compressed_form(bp, golden):
             with pytest.raises(bp.VerificationError):
                 bp.r1cs_proof_decompress(ctx, n, bytes(bad))
         ctx.close()
-    assert bp.lib().bp_r1cs_proof_compressed_bytes(0, 1 << 16) == 2549 and bp.lib().bp_r1cs_proof_bytes(0, 1 << 16) == 4288
+    assert bp.lib().bp_r1cs_proof_compressed_bytes(0, 1 << 16) == 2267 and bp.lib().bp_r1cs_proof_bytes(0, 1 << 16) == 4288
