@@ -103,6 +103,7 @@ SYMBOLS = {
     "bp_msm_g1_finish_host": (_I, [_I, _U8P, _SZ, _SZ, _I, _U8P]),
     "bp_msm_geometry": (_I, [_I, _SZ, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _P, _P, _U8P]),
     "bp_msm_record_from_affine": (_I, [_I, _U8P, _P]),
+    "bp_msm_record_positions": (_I, [_I, _SZ, _I, ctypes.POINTER(ctypes.c_int), _P]),
     "bp_msm_record_header": (_I, [_I, _SZ, _I, _P]),
     "bp_msm_g1_multi": (_I, [_PP, _PP, _PP, _SZ, _U8P]),
     "bp_ctx_trim": (_I, [_P]),
@@ -463,6 +464,14 @@ def msm_geometry(curve, n, window_bits=0):
     _check(lib().bp_msm_geometry(curve, n, window_bits, ctypes.byref(c), ctypes.byref(W), ctypes.cast(cw, ctypes.c_void_p),
                                  ctypes.cast(off, ctypes.c_void_p), bias), "bp_msm_geometry")
     return c.value, list(cw[:W.value]), list(off[:W.value]), int.from_bytes(bias.raw, "little")
+
+
+def msm_record_positions(curve, n, window_bits=0):
+    """-> [pos_r]: record r of a block carries weight 2^pos_r (bp_msm_record_positions)"""
+    k = ctypes.c_int()
+    pos = (ctypes.c_uint16 * 1024)()
+    _check(lib().bp_msm_record_positions(curve, n, window_bits, ctypes.byref(k), ctypes.cast(pos, ctypes.c_void_p)), "bp_msm_record_positions")
+    return list(pos[:k.value])
 
 
 def msm_record_from_affine(curve, point_le):

@@ -13,6 +13,9 @@ struct MsmGeom {
     int c;           // target window width
     WinTab tab;      // W windows of nearly equal width covering fr_bits + 1 bits
     uint32_t m;      // buckets per reduce thread
+    // tail records handed to the host: kRecPerWin per window; record r carries weight 2^rpos[r] (bp_host_tail.hpp folds any such list)
+    int nrec;
+    uint16_t rpos[kRecPerWin * kMaxWindows];
 };
 
 static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0) {
@@ -97,6 +100,8 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
     uint32_t rb = 0;
     for (int w = 0; w < W; w++) { t.rboff[w] = (uint16_t)rb; uint32_t B = t.boff[w + 1] - t.boff[w]; rb += ((B + m - 1) / m + kBlock - 1) / kBlock; }
     t.rboff[W] = (uint16_t)rb;   // <= 256 by the choice of m unless m hit its cap (c = 16, two sets, m = 16: 256)
+    for (int w = 0; w < W; w++) g.rpos[w] = t.off[w];
+    g.nrec = kRecPerWin * W;
 }
 
 // ------------------------------------------------------------------------------------------------ per-curve code
@@ -126,7 +131,7 @@ struct Impl {
         static const bool small_path = getenv("BP_SMALL_MSM") ? atoi(getenv("BP_SMALL_MSM")) != 0 : true;
         if (n <= kSmallMsmMax && small_path) {   // one launch: block per window, lane per term (k_small_msm)
             int rc0;
-            if ((rc0 = ctx->window_sum.reserve((size_t)W * kXyzzBytes))) return rc0;
+            if ((rc0 = ctx->window_sum.reserve((size_t)g.nrec * kXyzzBytes))) return rc0;
             const bool tm0 = ctx->timing;
             if (tm0) { if ((rc0 = ensure_events(ctx))) return rc0; for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st)); }
             hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
@@ -166,7 +171,7 @@ struct Impl {
         if ((rc = ctx->heavy_chunks.reserve(max_chunks * sizeof(uint2)))) return rc;
         if ((rc = ctx->meta.reserve((kTaskBins + 3) * 4))) return rc;
         if ((rc = ctx->partial.reserve((size_t)tab.rboff[W] * kXyzzBytes))) return rc;
-        if ((rc = ctx->window_sum.reserve((size_t)W * kXyzzBytes))) return rc;
+        if ((rc = ctx->window_sum.reserve((size_t)g.nrec * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // histogram, then bucket starts
         uint32_t* cursor = (uint32_t*)ctx->cursor.p;     // scatter cursors, then bucket ends
         uint32_t* ntasks = (uint32_t*)ctx->ntasks.p;
@@ -263,19 +268,6 @@ struct Impl {
 
     static const host::Tail<C>& tail() { static const host::Tail<C> t; return t; }
 
-    // Host stage (reference form, 30-bit-limb templates; the production path is host::Tail, bp_host_tail.hpp):
-    // fold `sets` sets of W window sums (host memory, packed XYZZ) into one affine point.
-    //   result = sum_w 2^(off_w) * (sum_s rec[s][w])     (Horner over the windows, cw[w] doublings per step)
-    static void fold_windows(const XyzzPacked<C>* rec, size_t sets, const MsmGeom& g, Aff<C>& out) {
-        const int W = g.tab.W;
-        Xyzz<C> acc = xyzz_inf<C>();
-        for (int w = W - 1; w >= 0; w--) {
-            if (!xyzz_is_inf(acc)) for (int i = 0; i < g.tab.cw[w]; i++) acc = xyzz_dbl(acc);
-            for (size_t s = 0; s < sets; s++) acc = xyzz_add(acc, xyzz_unpack(rec[s * W + w]));
-        }
-        out = xyzz_to_aff<C>(acc);
-    }
-
     static void aff_to_le(const Aff<C>& a, uint8_t* out) {
         uint32_t w[Fp::NW];
         fe_pack_words<Fp>(w, fe_from_mont<Fp>(a.x));
@@ -289,7 +281,7 @@ struct Impl {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
-        if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         if (ctx->device_tail) {   // all-device variant: one lane folds the windows (see k_tail_fold)
             if ((rc = ctx->scratch.reserve(2 * 4 * Fp::NW))) return rc;
             hipLaunchKernelGGL(k_tail_fold<C>, dim3(1), dim3(64), 0, ctx->stream, (const XyzzPacked<C>*)ctx->window_sum.p, g.tab, 0, g.tab.W,
@@ -300,10 +292,10 @@ struct Impl {
             collect_timing(ctx);
             return BP_OK;
         }
-        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, g.tab.W, g.tab.cw, out_le);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, g.nrec, g.rpos, out_le);
         return BP_OK;
     }
 
@@ -316,10 +308,10 @@ struct Impl {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
-        if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->pending_W = g.tab.W;                       // _end folds with the geometry that produced the records
-        memcpy(ctx->pending_cw, g.tab.cw, sizeof ctx->pending_cw);
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pending_nrec = g.nrec;                     // _end folds with the geometry that produced the records
+        memcpy(ctx->pending_rpos, g.rpos, sizeof ctx->pending_rpos);
         ctx->pending = true;
         return BP_OK;
     }
@@ -329,7 +321,7 @@ struct Impl {
         if (ctx->pending_n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, ctx->pending_W, ctx->pending_cw, out_le);
+        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, ctx->pending_nrec, ctx->pending_rpos, out_le);
         return BP_OK;
     }
 
@@ -339,25 +331,25 @@ struct Impl {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz);
         if (rc) return rc;
-        const int W = g.tab.W, W1 = W / 2;
-        if ((rc = host_pinned_reserve(ctx, (size_t)W * kXyzzBytes))) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        const int R1 = g.nrec / 2;                      // records of one scalar set
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
         // the two serial tails (~0.12 ms each: 255 dependent doublings) are independent: fold the second on the context's helper thread
         const host::Tail<C>& tl = tail();
         const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
-        const bool helped = ctx->worker.submit([&]() { tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le); });
-        tl.fold(rec, 1, W1, g.tab.cw, out1_le);
+        const bool helped = ctx->worker.submit([&]() { tl.fold(rec + R1, 1, R1, g.rpos + R1, out2_le); });
+        tl.fold(rec, 1, R1, g.rpos, out1_le);
         if (helped) ctx->worker.wait();
-        else tl.fold(rec + W1, 1, W1, g.tab.cw + W1, out2_le);   // no thread available: fold both here
+        else tl.fold(rec + R1, 1, R1, g.rpos + R1, out2_le);   // no thread available: fold both here
         return BP_OK;
     }
 
     // Record block of the two-stage (sharded) form: W window records followed by ONE header record that names the geometry
     // which produced them, so that bp_msm_g1_finish can refuse sets that do not fit together (ranks whose shard sizes straddle
     // a power of two pick different window widths unless the caller fixes c with bp_ctx_set_window_bits).
-    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, reserved; };   // widths: n_wide windows of cw_first bits, then cw_last
+    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, rec_per_win; };   // widths: n_wide windows of cw_first bits, then cw_last
     static_assert(sizeof(RecHeader) <= sizeof(XyzzPacked<C>), "header must fit one record");
     static constexpr uint32_t kRecMagic = 0x31575042u;   // "BPW1"
     static void fill_header(RecHeader& h, const MsmGeom& g) {
@@ -365,13 +357,14 @@ struct Impl {
         h.magic = kRecMagic; h.c = (uint32_t)g.c; h.W = (uint32_t)g.tab.W; h.fr_bits = (uint32_t)C::Fr::BITS;
         h.cw_first = g.tab.cw[0]; h.cw_last = g.tab.cw[g.tab.W - 1];
         for (int w = 0; w < g.tab.W; w++) if (g.tab.cw[w] == g.tab.cw[0]) h.n_wide++;
+        h.rec_per_win = kRecPerWin;
     }
 
     static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
-        const int W = g.tab.W;
+        const int W = g.nrec;
         HIPCHK(hipMemcpyAsync(device_out, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToDevice, ctx->stream));
         if ((rc = host_pinned_reserve(ctx, kXyzzBytes))) return rc;
         memset(ctx->host_pinned, 0, kXyzzBytes);
@@ -387,7 +380,7 @@ struct Impl {
     static int finish_host(int c_override, const XyzzPacked<C>* host_rec, size_t sets, size_t n_per_set, uint8_t* out_le) {
         MsmGeom g;
         msm_geom(g, C::Fr::BITS, n_per_set, c_override);
-        const int W = g.tab.W;
+        const int W = g.nrec;
         RecHeader want;
         fill_header(want, g);
         std::vector<XyzzPacked<C>> packed(sets * (size_t)W);
@@ -396,7 +389,7 @@ struct Impl {
             if (memcmp(&set[W], &want, sizeof want) != 0) return BP_ERR_ARG;     // geometry of this set differs from the caller's
             memcpy(&packed[s * (size_t)W], set, (size_t)W * kXyzzBytes);
         }
-        tail().fold(packed.data(), sets, W, g.tab.cw, out_le);
+        tail().fold(packed.data(), sets, W, g.rpos, out_le);
         return BP_OK;
     }
 
@@ -409,9 +402,9 @@ struct Impl {
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts->d, (const ScalarWords*)sc->d, pts->n, g);
         ctx->c_override = saved;
         if (rc) return rc;
-        if ((rc = host_pinned_reserve(ctx, (size_t)g.tab.W * kXyzzBytes))) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.tab.W * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
-        *W_out = g.tab.W;
+        if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        *W_out = g.nrec;
         return BP_OK;
     }
 
@@ -429,7 +422,7 @@ struct Impl {
     static int msm_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
         MsmGeom g;
         msm_geom(g, C::Fr::BITS, n_per_set, ctx->c_override);
-        size_t bytes = sets * (size_t)(g.tab.W + 1) * kXyzzBytes;
+        size_t bytes = sets * (size_t)(g.nrec + 1) * kXyzzBytes;
         int rc;
         if ((rc = host_pinned_reserve(ctx, bytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, device_records, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -853,7 +846,7 @@ size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {
     int bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
     MsmGeom g;
     msm_geom(g, bits, n, ctx->c_override);
-    return (size_t)g.tab.W + 1;   // W window records + the geometry header (see RecHeader)
+    return (size_t)g.nrec + 1;   // kRecPerWin records per window + the geometry header (see RecHeader)
 }
 
 size_t bp_msm_record_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? sizeof(XyzzPacked<Bls381>) : sizeof(XyzzPacked<Bn254>); }
@@ -885,6 +878,15 @@ int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_
     if (W_out) *W_out = g.tab.W;
     for (int w = 0; w < g.tab.W; w++) { if (cw_out) cw_out[w] = g.tab.cw[w]; if (off_out) off_out[w] = g.tab.off[w]; }
     if (bias_le32) memcpy(bias_le32, g.tab.bias.w, 32);
+    return BP_OK;
+}
+
+int bp_msm_record_positions(int curve_id, size_t n, int window_bits, int* nrec_out, uint16_t* pos_out) {
+    if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    MsmGeom g;
+    msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits);
+    if (nrec_out) *nrec_out = g.nrec;
+    if (pos_out) for (int r = 0; r < g.nrec; r++) pos_out[r] = g.rpos[r];
     return BP_OK;
 }
 
@@ -923,7 +925,7 @@ int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp
     if (n_max == 0) { memset(out_le, 0, pbytes); return BP_OK; }
     MsmGeom g;
     msm_geom(g, curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n_max, ctxs[0]->c_override);
-    const int c = g.c, W = g.tab.W;
+    const int c = g.c, W = g.nrec;
     std::vector<int> rcs(n_shards, BP_OK), Ws(n_shards, W);
     std::vector<char> queued(n_shards, 0), live(n_shards, 0);
     for (size_t i = 0; i < n_shards; i++) {
@@ -956,8 +958,8 @@ int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp
         all.insert(all.end(), (const uint8_t*)ctxs[i]->host_pinned, (const uint8_t*)ctxs[i]->host_pinned + (size_t)W * rec);
         sets++;
     }
-    if (curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().fold((const XyzzPacked<Bls381>*)all.data(), sets, W, g.tab.cw, out_le);
-    else Impl<Bn254>::tail().fold((const XyzzPacked<Bn254>*)all.data(), sets, W, g.tab.cw, out_le);
+    if (curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().fold((const XyzzPacked<Bls381>*)all.data(), sets, W, g.rpos, out_le);
+    else Impl<Bn254>::tail().fold((const XyzzPacked<Bn254>*)all.data(), sets, W, g.rpos, out_le);
     return BP_OK;
 }
 

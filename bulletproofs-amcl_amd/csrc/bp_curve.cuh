@@ -273,14 +273,14 @@ template <class C> BP_HD Xyzz<C> xyzz_lazy_to_strict(const XyzzLazy<C>& p) {
     return r;
 }
 
-// acc += q  (q canonical affine, possibly the identity)
-template <class C> BP_HD void xyzz_lazy_add_aff(XyzzLazy<C>& a, const Aff<C>& q) {
+// acc += q  (q canonical affine, possibly the identity).  M = multiplier policy (bp_field.cuh): MulInline / MulCall.
+template <class C, class M = MulInline> BP_HD void xyzz_lazy_add_aff(XyzzLazy<C>& a, const Aff<C>& q) {
     using Fp = typename C::Fp;
     if (aff_is_inf(q)) return;
     if (a.inf) { a = xyzz_lazy_from_strict(xyzz_from_aff(q)); return; }
     FeB<Fp, 1> qx = feb_from_strict<Fp>(q.x), qy = feb_from_strict<Fp>(q.y);
-    FeB<Fp, 2> U2 = feb_mul(qx, a.zz);
-    FeB<Fp, 2> S2 = feb_mul(qy, a.zzz);
+    FeB<Fp, 2> U2 = M::mul(qx, a.zz);
+    FeB<Fp, 2> S2 = M::mul(qy, a.zzz);
     FeB<Fp, 10> Pp = feb_sub<8>(U2, a.x);
     FeB<Fp, 6> Rr = feb_sub<4>(S2, a.y);
     if (feb_is_zero_mod_p(Pp)) {
@@ -288,17 +288,124 @@ template <class C> BP_HD void xyzz_lazy_add_aff(XyzzLazy<C>& a, const Aff<C>& q)
         else a = xyzz_lazy_inf<C>();                                                // acc == -q
         return;
     }
-    FeB<Fp, 2> PP = feb_sqr(Pp);
-    FeB<Fp, 2> PPP = feb_mul(Pp, PP);
-    FeB<Fp, 2> Q = feb_mul(a.x, PP);
-    FeB<Fp, 2> R2 = feb_sqr(Rr);
+    FeB<Fp, 2> PP = M::sqr(Pp);
+    FeB<Fp, 2> PPP = M::mul(Pp, PP);
+    FeB<Fp, 2> Q = M::mul(a.x, PP);
+    FeB<Fp, 2> R2 = M::sqr(Rr);
     FeB<Fp, 8> X3 = feb_sub<2>(feb_sub<2>(feb_sub<2>(R2, PPP), Q), Q);
     FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
-    FeB<Fp, 4> Y3 = feb_sub<2>(feb_mul(Rr, QX), feb_mul(a.y, PPP));
-    a.zz = feb_mul(a.zz, PP);
-    a.zzz = feb_mul(a.zzz, PPP);
+    FeB<Fp, 4> Y3 = feb_sub<2>(M::mul(Rr, QX), M::mul(a.y, PPP));
+    a.zz = M::mul(a.zz, PP);
+    a.zzz = M::mul(a.zzz, PPP);
     a.x = X3;
     a.y = Y3;
+}
+
+// ----------------------------------------------------------------------------------------------- lazy full addition / doubling
+// The same bounded domain for bucket-sum + bucket-sum additions (tree sums, the digit-sum reduce, the small-MSM path):
+//     X < 8p,  Y < 4p,  ZZ < 2p,  ZZZ < 2p   on both operands and on the result.
+// add-2008-s:
+//     U1 = X1 ZZ2 (8*2)  U2 = X2 ZZ1   S1 = Y1 ZZZ2 (4*2)  S2 = Y2 ZZZ1            all < 2p
+//     P = U2 - U1 + 2p < 4p            R = S2 - S1 + 2p < 4p
+//     PP = P^2 (16)   PPP = P PP (8)   Q = U1 PP (4)                                 all < 2p
+//     X3 = R^2 - PPP - Q - Q (+2p each) < 8p        Y3 = R (Q - X3 + 8p) - S1 PPP + 2p   (4*10, 2*2)  < 4p
+//     ZZ3 = (ZZ1 ZZ2) PP,  ZZZ3 = (ZZZ1 ZZZ2) PPP                                    < 2p
+// dbl-2008-s-1 (a = 0):
+//     U = 2Y < 8p   V = U^2 (64)   W = U V (16)   S = X V (16)   M = 3 X^2 (64 -> 3 * 2p = 6p)
+//     X3 = M^2 - S - S (36; +2p each) < 6p          Y3 = M (S - X3 + 8p) - W Y + 2p   (6*10, 2*4)  < 4p
+//     ZZ3 = V ZZ,  ZZZ3 = W ZZZ
+// No conditional subtraction (no v_cndmask: 22 cycles per wave instruction on gfx950) anywhere on these paths.
+// A lazy point is stored PACKED without canonicalisation when 8p < 2^(32 NW) (BLS12-381: 8p < 2^384); for BN254
+// (4p < 2^256 < 8p) X is brought below 4p first.  The host tail reduces on entry (bp_host_tail.hpp).
+template <class C, class M = MulInline> BP_HD XyzzLazy<C> xyzz_lazy_dbl(const XyzzLazy<C>& a) {
+    using Fp = typename C::Fp;
+    if (a.inf) return a;
+    FeB<Fp, 8> U = feb_add(a.y, a.y);
+    FeB<Fp, 2> V = M::sqr(U);
+    FeB<Fp, 2> W = M::mul(U, V);
+    FeB<Fp, 2> S = M::mul(a.x, V);
+    FeB<Fp, 2> X2 = M::sqr(a.x);
+    FeB<Fp, 6> Mm = feb_add(feb_add(X2, X2), X2);
+    XyzzLazy<C> r;
+    FeB<Fp, 6> X3 = feb_sub<2>(feb_sub<2>(M::sqr(Mm), S), S);
+    FeB<Fp, 10> SX = feb_sub<8>(S, X3);
+    r.y = feb_sub<2>(M::mul(Mm, SX), M::mul(W, a.y));
+    r.x = feb_widen<8>(X3);
+    r.zz = M::mul(V, a.zz);
+    r.zzz = M::mul(W, a.zzz);
+    r.inf = false;
+    return r;
+}
+
+template <class C, class M = MulInline> BP_HD XyzzLazy<C> xyzz_lazy_add(const XyzzLazy<C>& a, const XyzzLazy<C>& b) {
+    using Fp = typename C::Fp;
+    if (b.inf) return a;
+    if (a.inf) return b;
+    FeB<Fp, 2> U1 = M::mul(a.x, b.zz);
+    FeB<Fp, 2> U2 = M::mul(b.x, a.zz);
+    FeB<Fp, 2> S1 = M::mul(a.y, b.zzz);
+    FeB<Fp, 2> S2 = M::mul(b.y, a.zzz);
+    FeB<Fp, 4> Pp = feb_sub<2>(U2, U1);
+    FeB<Fp, 4> Rr = feb_sub<2>(S2, S1);
+    if (feb_is_zero_mod_p(Pp)) {
+        if (feb_is_zero_mod_p(Rr)) return xyzz_lazy_dbl<C, M>(a);
+        return xyzz_lazy_inf<C>();
+    }
+    FeB<Fp, 2> PP = M::sqr(Pp);
+    FeB<Fp, 2> PPP = M::mul(Pp, PP);
+    FeB<Fp, 2> Q = M::mul(U1, PP);
+    FeB<Fp, 8> X3 = feb_sub<2>(feb_sub<2>(feb_sub<2>(M::sqr(Rr), PPP), Q), Q);
+    FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
+    XyzzLazy<C> r;
+    r.y = feb_sub<2>(M::mul(Rr, QX), M::mul(S1, PPP));
+    r.x = X3;
+    r.zz = M::mul(M::mul(a.zz, b.zz), PP);
+    r.zzz = M::mul(M::mul(a.zzz, b.zzz), PPP);
+    r.inf = false;
+    return r;
+}
+
+// packed memory form of a lazy point (identity <=> ZZ = 0); values below 2^(32 NW) as explained above
+template <class C> BP_HD XyzzPacked<C> xyzz_lazy_pack(const XyzzLazy<C>& p) {
+    using Fp = typename C::Fp;
+    XyzzPacked<C> r;
+    if (p.inf) {
+        for (int i = 0; i < Fp::NW; i++) { r.x.w[i] = 0; r.y.w[i] = 0; r.zz.w[i] = 0; r.zzz.w[i] = 0; }
+        return r;
+    }
+    constexpr bool kFits8p = Fp::BITS + 3 <= 32 * Fp::NW;
+    Fe<Fp> x;
+    for (int i = 0; i < Fp::NL; i++) x.v[i] = p.x.v[i];
+    if (!kFits8p) {   // one conditional subtraction of 4p
+        uint32_t d[Fp::NL];
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < Fp::NL; i++) { uint32_t t = x.v[i] - Lazy<Fp>::L.kp[2][i] - br; br = t >> 31; d[i] = t & LMASK; }
+        const uint32_t keep = 0u - br;   // all ones: x < 4p, keep x
+#pragma unroll
+        for (int i = 0; i < Fp::NL; i++) x.v[i] = (x.v[i] & keep) | (d[i] & ~keep);
+    }
+    fe_pack_words<Fp>(r.x.w, x);
+    Fe<Fp> t;
+    for (int i = 0; i < Fp::NL; i++) t.v[i] = p.y.v[i];
+    fe_pack_words<Fp>(r.y.w, t);
+    for (int i = 0; i < Fp::NL; i++) t.v[i] = p.zz.v[i];
+    fe_pack_words<Fp>(r.zz.w, t);
+    for (int i = 0; i < Fp::NL; i++) t.v[i] = p.zzz.v[i];
+    fe_pack_words<Fp>(r.zzz.w, t);
+    // a non-identity point whose ZZ happens to be = 0 mod p cannot occur (ZZ is a product of non-zero differences), but its
+    // packed words could all be zero only if ZZ = 0 exactly, which the bounded domain never produces for a finite point
+    return r;
+}
+
+template <class C> BP_HD XyzzLazy<C> xyzz_lazy_unpack(const XyzzPacked<C>& p) {
+    using Fp = typename C::Fp;
+    XyzzLazy<C> r;
+    Fe<Fp> x = fe_unpack_words<Fp>(p.x.w), y = fe_unpack_words<Fp>(p.y.w), zz = fe_unpack_words<Fp>(p.zz.w), zzz = fe_unpack_words<Fp>(p.zzz.w);
+    uint32_t any = 0;
+    for (int i = 0; i < Fp::NL; i++) { r.x.v[i] = x.v[i]; r.y.v[i] = y.v[i]; r.zz.v[i] = zz.v[i]; r.zzz.v[i] = zzz.v[i]; any |= zz.v[i]; }
+    r.inf = any == 0;
+    return r;
 }
 
 }  // namespace bp

@@ -517,4 +517,56 @@ template <class P, int B> BP_HD bool feb_is_zero_mod_p(const FeB<P, B>& a) {
     return fe_is_zero(s);
 }
 
+// ----------------------------------------------------------------------------------------------- out-of-line multiplier
+// A fully inlined point addition is ~50 KB of straight-line code (14 products of ~3.5 KB).  The hot accumulate loop wants
+// exactly that, but every SHORT kernel around it -- bucket reduce, tree sums, the one-launch small MSM, IPP folds -- executes
+// each inlined copy only a handful of times, and on gfx950 the first pass through cold code is paced by instruction fetch
+// from HBM (measured: 0.2-0.4 ms per launch that do not depend on n, profiles/r02_*), i.e. longer than the arithmetic.
+// Those kernels use the multiplier as a real function (one 3.5 KB body per field, shared by every call site, resident in
+// the instruction cache after its first use); the call costs a few dozen register moves per product.
+template <class P> struct LimbsV { uint32_t v[P::NL]; };
+
+template <class P> BP_HD_NOINLINE LimbsV<P> feb_mul_outlined(LimbsV<P> a, LimbsV<P> b) {
+    FeB<P, 8> x, y;
+    for (int i = 0; i < P::NL; i++) { x.v[i] = a.v[i]; y.v[i] = b.v[i]; }
+    FeB<P, 2> r = feb_mul(x, y);          // the bound is the caller's business (checked in MulCall below)
+    LimbsV<P> o;
+    for (int i = 0; i < P::NL; i++) o.v[i] = r.v[i];
+    return o;
+}
+template <class P> BP_HD_NOINLINE LimbsV<P> feb_sqr_outlined(LimbsV<P> a) {
+    FeB<P, 8> x;
+    for (int i = 0; i < P::NL; i++) x.v[i] = a.v[i];
+    FeB<P, 2> r = feb_sqr(x);
+    LimbsV<P> o;
+    for (int i = 0; i < P::NL; i++) o.v[i] = r.v[i];
+    return o;
+}
+
+// multiplier policies for the curve formulas: same bounds, same results; Inline for the accumulate loop, Call elsewhere
+struct MulInline {
+    template <class P, int B1, int B2> static BP_HD FeB<P, 2> mul(const FeB<P, B1>& a, const FeB<P, B2>& b) { return feb_mul(a, b); }
+    template <class P, int B1> static BP_HD FeB<P, 2> sqr(const FeB<P, B1>& a) { return feb_sqr(a); }
+};
+struct MulCall {
+    template <class P, int B1, int B2> static BP_HD FeB<P, 2> mul(const FeB<P, B1>& a, const FeB<P, B2>& b) {
+        static_assert(B1 * B2 <= kMaxProd, "operands too large for a lazy Montgomery product");
+        LimbsV<P> x, y;
+        for (int i = 0; i < P::NL; i++) { x.v[i] = a.v[i]; y.v[i] = b.v[i]; }
+        LimbsV<P> o = feb_mul_outlined<P>(x, y);
+        FeB<P, 2> r;
+        for (int i = 0; i < P::NL; i++) r.v[i] = o.v[i];
+        return r;
+    }
+    template <class P, int B1> static BP_HD FeB<P, 2> sqr(const FeB<P, B1>& a) {
+        static_assert(B1 * B1 <= kMaxProd, "operand too large for a lazy Montgomery square");
+        LimbsV<P> x;
+        for (int i = 0; i < P::NL; i++) x.v[i] = a.v[i];
+        LimbsV<P> o = feb_sqr_outlined<P>(x);
+        FeB<P, 2> r;
+        for (int i = 0; i < P::NL; i++) r.v[i] = o.v[i];
+        return r;
+    }
+};
+
 }  // namespace bp

@@ -147,6 +147,12 @@ class Tail {
         return p;
     }
 
+    static bool is_identity_record(const XyzzPacked<C>& r) {
+        uint32_t o = 0;
+        for (int i = 0; i < Fp::NW; i++) o |= r.zz.w[i];
+        return o == 0;
+    }
+
 public:
     Tail() {
         // k = 2^(128 N - 30 NL) mod p, plain integer:  mul(a, k) = a * k / 2^(64N) = a * 2^(64N) / 2^(30NL)
@@ -162,14 +168,30 @@ public:
         memcpy(dev_to_host, t, sizeof t);
     }
 
-    // result = sum_w 2^(off_w) (sum_s rec[s][w]) as canonical little-endian x || y (all-zero = identity)
-    void fold(const XyzzPacked<C>* rec, size_t sets, int W, const uint8_t* cw, uint8_t* out_le) const {
+    // result = sum_r 2^(pos[r]) (sum_s rec[s * nrec + r]) as canonical little-endian x || y (all-zero = identity): Horner over the
+    // records in descending bit position, pos[r] - pos[next] doublings in between (~255 in all, whatever the record count).
+    void fold(const XyzzPacked<C>* rec, size_t sets, int nrec, const uint16_t* pos, uint8_t* out_le) const {
         Jac acc; acc.inf = true;
         memset(acc.x, 0, sizeof acc.x); memset(acc.y, 0, sizeof acc.y); memset(acc.z, 0, sizeof acc.z);
-        for (int w = W - 1; w >= 0; w--) {
-            for (int i = 0; i < cw[w]; i++) dbl(acc);
-            for (size_t s = 0; s < sets; s++) add(acc, from_record(rec[s * W + w]));
+        // order of the records by descending position (bucket lists over the bit positions)
+        constexpr int kMaxPos = 600;
+        int head[kMaxPos + 1];
+        for (int p = 0; p <= kMaxPos; p++) head[p] = -1;
+        int* next = new int[nrec > 0 ? nrec : 1];
+        for (int r = 0; r < nrec; r++) { int p = pos[r] <= kMaxPos ? pos[r] : kMaxPos; next[r] = head[p]; head[p] = r; }
+        int cur = -1;
+        for (int p = kMaxPos; p >= 0; p--) {
+            for (int r = head[p]; r >= 0; r = next[r]) {
+                bool any = false;
+                for (size_t s = 0; s < sets && !any; s++) any = !is_identity_record(rec[s * (size_t)nrec + r]);
+                if (!any) continue;
+                if (cur >= 0) for (int i = 0; i < cur - p; i++) dbl(acc);
+                cur = p;
+                for (size_t s = 0; s < sets; s++) add(acc, from_record(rec[s * (size_t)nrec + r]));
+            }
         }
+        delete[] next;
+        for (int i = 0; i < cur; i++) dbl(acc);
         const int fb = 4 * Fp::NW;
         memset(out_le, 0, 2 * fb);
         if (acc.inf) return;

@@ -161,8 +161,8 @@ struct bp_ctx {
     HostWorker worker;
     DevBuf flags;                       // 64 B of device error flags (point / scalar validation)
     // geometry of the MSM queued by bp_msm_g1_begin (consumed by _end; bp_ctx_set_window_bits in between cannot disturb it)
-    int pending_W = 0;
-    uint8_t pending_cw[256] = {};
+    int pending_nrec = 0;
+    uint16_t pending_rpos[bp::kRecPerWin * bp::kMaxWindows] = {};
 };
 
 // RAII block from a context's pool (temporaries inside one call)

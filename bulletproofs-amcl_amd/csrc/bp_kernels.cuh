@@ -56,6 +56,7 @@ struct WinTab {
     uint16_t rboff[kMaxWindows + 1];   // first block of window w in the (compact, 1-D) grid of k_bucket_reduce
     ScalarWords bias;   // H = sum_w (2^(cw-1) - 1) 2^off[w]
 };
+constexpr int kRecPerWin = 1;          // tail records per window handed to the host (record r carries weight 2^rpos[r], bp_capi.hip)
 
 constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane)
 constexpr int kMaxBinRows = 4096;      // sum over windows of coarse bins (c = 16: 16 x 128 per scalar set)
@@ -361,23 +362,27 @@ __global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* 
         if (code >> 31) p.y = fe_neg(p.y);
         xyzz_lazy_add_aff(acc, p);
     }
-    tsum[tid] = xyzz_pack(xyzz_lazy_to_strict(acc));
+    tsum[tid] = xyzz_lazy_pack(acc);     // bounded, not canonical: every consumer works in the same lazy domain
 }
 
 // ---------------------------------------------------------------------------------------------- bucket reduce
 // LDS tree over the block's kBlock partial sums (packed, 4*NW words each); result valid in thread 0.
 // `active` = number of leading threads that can hold a non-identity value (the tree starts at the first power of two
 // that covers them: small MSMs have a handful of segments per window, not 256).
+// All bucket-sum + bucket-sum arithmetic from here on is in the bounded ("lazy") domain of bp_curve.cuh: no conditional
+// subtraction (v_cndmask costs 22 cycles per wave instruction on gfx950), 17.2 instead of 20.7 us per dependent addition at
+// one wave per SIMD (microbench/point_latency.hip); records stay in that domain in memory and the host reduces on entry.
 template <class C>
-__device__ __forceinline__ Xyzz<C> block_tree_sum(Xyzz<C> mine, XyzzPacked<C>* lds, int active = kBlock) {
-    lds[threadIdx.x] = xyzz_pack(mine);
+__device__ __forceinline__ XyzzLazy<C> block_tree_sum(XyzzLazy<C> mine, XyzzPacked<C>* lds, int active = kBlock) {
+    lds[threadIdx.x] = xyzz_lazy_pack(mine);
     __syncthreads();
     int s0 = kBlock / 2;
     while (s0 >= active && s0 > 0) s0 >>= 1;   // largest stride with a live partner
+#pragma unroll 1
     for (int s = s0; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
-            mine = xyzz_add(mine, xyzz_unpack(lds[threadIdx.x + s]));
-            lds[threadIdx.x] = xyzz_pack(mine);
+            mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(lds[threadIdx.x + s]));
+            lds[threadIdx.x] = xyzz_lazy_pack(mine);
         }
         __syncthreads();
     }
@@ -400,9 +405,9 @@ __global__ void __launch_bounds__(kBlock) k_combine_chunks(const uint2* __restri
         const uint2 gc = chunks[c];
         const uint32_t first = task_off[gc.x] + gc.y * kBlock, left = ntasks[gc.x] - gc.y * kBlock;
         const uint32_t cnt = left < (uint32_t)kBlock ? left : (uint32_t)kBlock;
-        Xyzz<C> mine = threadIdx.x < cnt ? xyzz_unpack(tsum[first + threadIdx.x]) : xyzz_inf<C>();
+        XyzzLazy<C> mine = threadIdx.x < cnt ? xyzz_lazy_unpack(tsum[first + threadIdx.x]) : xyzz_lazy_inf<C>();
         mine = block_tree_sum<C>(mine, lds, (int)cnt);
-        if (threadIdx.x == 0) tsum[first] = xyzz_pack(mine);
+        if (threadIdx.x == 0) tsum[first] = xyzz_lazy_pack(mine);
         __syncthreads();   // lds is reused by the next chunk
     }
 }
@@ -417,11 +422,11 @@ __global__ void __launch_bounds__(kBlock) k_combine_heavy(const uint32_t* __rest
         const uint32_t g = heavy[h];
         const uint32_t t0 = task_off[g], nch = (ntasks[g] + kBlock - 1) / kBlock;
         if (nch < 2) continue;   // a single chunk: k_combine_chunks already left the sum in tsum[t0] (uniform per block)
-        Xyzz<C> mine = xyzz_inf<C>();
-        for (uint32_t k = threadIdx.x; k < nch; k += kBlock) mine = xyzz_add(mine, xyzz_unpack(tsum[t0 + k * kBlock]));
+        XyzzLazy<C> mine = xyzz_lazy_inf<C>();
+        for (uint32_t k = threadIdx.x; k < nch; k += kBlock) mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(tsum[t0 + k * kBlock]));
         __syncthreads();   // all chunk sums read before tsum[t0] is overwritten
         mine = block_tree_sum<C>(mine, lds, nch < (uint32_t)kBlock ? (int)nch : kBlock);
-        if (threadIdx.x == 0) tsum[t0] = xyzz_pack(mine);
+        if (threadIdx.x == 0) tsum[t0] = xyzz_lazy_pack(mine);
         __syncthreads();
     }
 }
@@ -439,12 +444,30 @@ __device__ __forceinline__ Xyzz<C> xyzz_mul_small(uint32_t k, const Xyzz<C>& p) 
     return acc;
 }
 
+// small * p by double-and-add (small < 2^16)
+template <class C>
+__device__ __forceinline__ XyzzLazy<C> xyzz_mul_small(uint32_t k, const XyzzLazy<C>& p) {
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+    if (k == 0) return acc;
+#pragma unroll 1
+    for (int i = 31 - __clz(k); i >= 0; i--) {
+        acc = xyzz_lazy_dbl(acc);
+        if ((k >> i) & 1) acc = xyzz_lazy_add(acc, p);
+    }
+    return acc;
+}
+
 // grid = tab.rboff[W] blocks, window w owning blocks rboff[w] .. rboff[w+1]-1 (exactly the blocks that have buckets: with a
 // 2-D grid padded to the widest window, the blocks that exit at once skewed the dispatch and some CUs ran two of these long
 // dependent chains back to back -- 1.00 ms instead of 0.54 ms at n = 2^16, c = 14; profiles/r01_reduce_grid_*.txt).
 // Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket indices t*m .. t*m + m - 1, and produces
 //   sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
 // Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
+// (Round 2 tried to replace this by plain "digit sums" of the bucket values -- 2 independent additions per bucket, ~25 dependent
+// steps instead of ~46, weights left to the host's doubling chain.  It lost: every dependent step of a lone wave costs 17-20 us
+// whatever the formulation, the wave-level trees idle most lanes, and each extra ~50 KB of inlined addition code a kernel
+// touches costs ~0.1-0.2 ms of cold instruction fetch per launch (profiles/r02_digit_sum_experiment.txt).  One balanced wave
+// per SIMD running this chain is the fastest form measured.)
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t m,
@@ -456,9 +479,9 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
     uint32_t B = tab.boff[w + 1] - tab.boff[w];
     uint32_t t = bx * kBlock + threadIdx.x;
     uint32_t T = (B + m - 1) / m;
-    Xyzz<C> mine = xyzz_inf<C>();
+    XyzzLazy<C> mine = xyzz_lazy_inf<C>();
     if (t < T) {
-        Xyzz<C> run = xyzz_inf<C>(), tri = xyzz_inf<C>();
+        XyzzLazy<C> run = xyzz_lazy_inf<C>(), tri = xyzz_lazy_inf<C>();
         uint32_t lo = t * m, hi = lo + m < B ? lo + m : B;
         for (uint32_t j = hi; j-- > lo;) {
             uint32_t g = tab.boff[w] + j;
@@ -467,15 +490,15 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
                 // a bucket cut into 2..kLightMax tasks is summed here (a separate lane-per-bucket kernel for it cost 0.1-0.2 ms
                 // at n = 2^16); a heavier bucket was already folded into its first record by k_combine_chunks / _heavy
                 uint32_t t0 = task_off[g], lim = nt <= kLightMax ? nt : 1;
-                for (uint32_t k = 0; k < lim; k++) run = xyzz_add(run, xyzz_unpack(tsum[t0 + k]));
+                for (uint32_t k = 0; k < lim; k++) run = xyzz_lazy_add(run, xyzz_lazy_unpack(tsum[t0 + k]));
             }
-            tri = xyzz_add(tri, run);
+            tri = xyzz_lazy_add(tri, run);
         }
-        mine = xyzz_add(tri, xyzz_mul_small<C>(lo, run));
+        mine = xyzz_lazy_add(tri, xyzz_mul_small<C>(lo, run));
     }
     uint32_t live = T - bx * kBlock;
     mine = block_tree_sum<C>(mine, lds, live < (uint32_t)kBlock ? (int)live : kBlock);
-    if (threadIdx.x == 0) partial[blockIdx.x] = xyzz_pack(mine);
+    if (threadIdx.x == 0) partial[blockIdx.x] = xyzz_lazy_pack(mine);
 }
 
 // grid = W blocks: window_sum[w] = sum of partial[rboff[w] .. rboff[w+1])
@@ -484,10 +507,10 @@ __global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __r
     __shared__ XyzzPacked<C> lds[kBlock];
     uint32_t w = blockIdx.x;
     const uint32_t first = tab.rboff[w], per_window = tab.rboff[w + 1] - first;
-    Xyzz<C> mine = xyzz_inf<C>();
-    for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_add(mine, xyzz_unpack(partial[first + j]));
+    XyzzLazy<C> mine = xyzz_lazy_inf<C>();
+    for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(partial[first + j]));
     mine = block_tree_sum<C>(mine, lds, per_window < (uint32_t)kBlock ? (int)per_window : kBlock);
-    if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
+    if (threadIdx.x == 0) window_sum[w] = xyzz_lazy_pack(mine);
 }
 
 // ---------------------------------------------------------------------------------------------- small MSM (n <= kSmallMsmMax)
@@ -511,7 +534,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
     __shared__ XyzzPacked<C> lds[kBlock];
     const int w = blockIdx.x, wps = tab.W / tab.nsets, set = w / wps;
     const int cw = tab.cw[w], off = tab.off[w];
-    Xyzz<C> mine = xyzz_inf<C>();
+    XyzzLazy<C> mine = xyzz_lazy_inf<C>();
     for (uint32_t t = threadIdx.x; t < n; t += kBlock) {      // kSmallMsmMax / kBlock terms per lane at most
         uint64_t q[4];
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
@@ -519,15 +542,16 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         if (d == 0) continue;
         Aff<C> p = aff_unpack(pts[t]);
         if (d < 0) { p.y = fe_neg(p.y); d = -d; }
-        Xyzz<C> acc = xyzz_from_aff(p);
+        XyzzLazy<C> acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
+#pragma unroll 1
         for (int i = 30 - __clz(d); i >= 0; i--) {            // bits below the leading one
-            acc = xyzz_dbl(acc);
-            if ((d >> i) & 1) acc = xyzz_add_aff(acc, p);
+            acc = xyzz_lazy_dbl(acc);
+            if ((d >> i) & 1) xyzz_lazy_add_aff(acc, p);
         }
-        mine = xyzz_add(mine, acc);
+        mine = xyzz_lazy_add(mine, acc);
     }
     mine = block_tree_sum<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
-    if (threadIdx.x == 0) window_sum[w] = xyzz_pack(mine);
+    if (threadIdx.x == 0) window_sum[w] = xyzz_lazy_pack(mine);
 }
 
 // ---------------------------------------------------------------------------------------------- device tail (optional)
@@ -538,12 +562,14 @@ template <class C>
 __global__ void __launch_bounds__(64) k_tail_fold(const XyzzPacked<C>* __restrict__ wsum, WinTab tab, int w_begin, int w_end, uint32_t* __restrict__ out_le) {
     using Fp = typename C::Fp;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Xyzz<C> acc = xyzz_inf<C>();
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+#pragma unroll 1
     for (int w = w_end - 1; w >= w_begin; w--) {
-        for (int i = 0; i < tab.cw[w]; i++) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, xyzz_unpack(wsum[w]));
+#pragma unroll 1
+        for (int i = 0; i < tab.cw[w]; i++) acc = xyzz_lazy_dbl(acc);
+        acc = xyzz_lazy_add(acc, xyzz_lazy_unpack(wsum[w]));
     }
-    Aff<C> a = xyzz_to_aff<C>(acc);
+    Aff<C> a = xyzz_to_aff<C>(xyzz_lazy_to_strict(acc));
     uint32_t xw[Fp::NW], yw[Fp::NW];
     fe_pack_words<Fp>(xw, fe_from_mont<Fp>(a.x));
     fe_pack_words<Fp>(yw, fe_from_mont<Fp>(a.y));

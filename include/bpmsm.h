@@ -164,9 +164,9 @@ int bp_msm_g1_end(bp_ctx* ctx, uint8_t* out_le);
  * (src/ipp.rs:148-170), as are commitments that share the generator vector (src/r1cs/prover.rs:347-362). */
 int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1, const bp_frvec* scalars2, uint8_t* out1_le, uint8_t* out2_le);
 /* Two-stage form used when the index range is sharded over several GPUs (one process per GPU).
- * Stage 1 (device): each rank runs the bucket pipeline on its own slice and leaves its W per-window bucket sums
- * ("window records", un-normalised XYZZ, bp_msm_record_bytes() each, bp_msm_window_records(ctx, n) of them) in a
- * caller-owned HBM buffer.  The caller all-gathers the N ranks' records over RCCL (point addition is not an RCCL
+ * Stage 1 (device): each rank runs the bucket pipeline on its own slice and leaves its partial sums ("records":
+ * un-normalised XYZZ points with a power-of-two weight each, bp_msm_record_bytes() bytes, bp_msm_window_records(ctx, n) of them
+ * including the header) in a caller-owned HBM buffer.  The caller all-gathers the N ranks' records over RCCL (point addition is not an RCCL
  * reduction op; N*W*192 B is latency-bound).  Stage 2 (bp_msm_g1_finish): one D2H copy of `sets`
  * record sets, per-window sum, the serial 2^(c w) fold and the affine normalisation, giving BP_FMT_LE bytes.
  * A record block is W window records followed by ONE header record naming the geometry (c, W, widths) that produced it;
@@ -188,6 +188,10 @@ int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, s
  * off[W], and the recoding bias (window w of k + bias, minus 2^(cw-1) - 1, is the signed digit of window w).  Any output
  * pointer may be NULL. */
 int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32);
+/* A record block holds nrec records (one per window in this version; the host fold accepts any list) and its header; record r
+ * carries weight 2^pos[r]:  result = sum_r 2^pos[r] * record[r].  nrec = bp_msm_window_records() - 1; pos_out needs room for
+ * 256 entries. */
+int bp_msm_record_positions(int curve_id, size_t n, int window_bits, int* nrec_out, uint16_t* pos_out);
 /* Record-block helpers for hosts that build or check blocks themselves (tests, aggregators): an affine point as a window
  * record, and the header record of the geometry above.  Host arithmetic. */
 int bp_msm_record_from_affine(int curve_id, const uint8_t* point_le, void* record_out);

@@ -15,7 +15,7 @@ bp = G.load_package()
 def rand_scalars(ctx, n, seed):
     rng = np.random.default_rng(seed)
     a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-    a[:, 31] &= 0x3F            # < 2^254 < r for both curves
+    a[:, 31] &= 0x1F            # < 2^253 < r for both curves (uploads reject scalars >= r)
     return a.tobytes()
 
 

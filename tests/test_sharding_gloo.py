@@ -31,8 +31,10 @@ lo, hi = sharding.shard_range(n, world, rank)
 c = sharding.common_window_bits(bp, curve, n, world)
 nmax = sharding.largest_shard(n, world)
 _, cw, off, bias = bp.msm_geometry(curve, nmax, c)
-# device stage, played by the oracle: S_w = sum_i digit_w(k_i) P_i over this rank's index range
-block = b""
+# device stage, played by the oracle: S_w = sum_i digit_w(k_i) P_i over this rank's index range, placed in the record of weight 2^off_w
+pos = bp.msm_record_positions(curve, nmax, c)
+zero = bytes(bp.msm_record_bytes(curve))
+recs = [zero] * len(pos)
 for w in range(len(cw)):
     digs = b""
     for i in range(lo, hi):
@@ -40,7 +42,9 @@ for w in range(len(cw)):
         d = ((k >> off[w]) & ((1 << cw[w]) - 1)) - ((1 << (cw[w] - 1)) - 1)
         digs += (d %% r).to_bytes(32, "little")
     S = O.msm(curve, pts[lo * 96:hi * 96], digs, hi - lo, algo=O.PIPPENGER)
-    block += bp.msm_record_from_affine(curve, S)
+    slot = next(j for j in range(len(pos)) if pos[j] == off[w] and recs[j] is zero)
+    recs[slot] = bp.msm_record_from_affine(curve, S)
+block = b"".join(recs)
 block += bp.msm_record_header(curve, nmax, c)
 mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
 allrec = sharding.all_gather_records(mine, world)
