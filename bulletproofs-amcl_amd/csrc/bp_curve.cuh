@@ -294,7 +294,8 @@ template <class C, class M = MulInline> BP_HD void xyzz_lazy_add_aff(XyzzLazy<C>
     FeB<Fp, 2> R2 = M::sqr(Rr);
     FeB<Fp, 8> X3 = feb_sub<2>(feb_sub<2>(feb_sub<2>(R2, PPP), Q), Q);
     FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
-    FeB<Fp, 4> Y3 = feb_sub<2>(M::mul(Rr, QX), M::mul(a.y, PPP));
+    // Y3 = R (Q - X3) - Y PPP as R (Q - X3) + (4p - Y) PPP with ONE reduction (6*10 + 4*2 <= kMaxProd)
+    FeB<Fp, 4> Y3 = feb_widen<4>(M::mul_add_mul(Rr, QX, feb_neg<4>(a.y), PPP));
     a.zz = M::mul(a.zz, PP);
     a.zzz = M::mul(a.zzz, PPP);
     a.x = X3;
@@ -329,7 +330,7 @@ template <class C, class M = MulInline> BP_HD XyzzLazy<C> xyzz_lazy_dbl(const Xy
     XyzzLazy<C> r;
     FeB<Fp, 6> X3 = feb_sub<2>(feb_sub<2>(M::sqr(Mm), S), S);
     FeB<Fp, 10> SX = feb_sub<8>(S, X3);
-    r.y = feb_sub<2>(M::mul(Mm, SX), M::mul(W, a.y));
+    r.y = feb_widen<4>(M::mul_add_mul(Mm, SX, W, feb_neg<4>(a.y)));      // 6*10 + 2*4
     r.x = feb_widen<8>(X3);
     r.zz = M::mul(V, a.zz);
     r.zzz = M::mul(W, a.zzz);
@@ -357,7 +358,7 @@ template <class C, class M = MulInline> BP_HD XyzzLazy<C> xyzz_lazy_add(const Xy
     FeB<Fp, 8> X3 = feb_sub<2>(feb_sub<2>(feb_sub<2>(M::sqr(Rr), PPP), Q), Q);
     FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
     XyzzLazy<C> r;
-    r.y = feb_sub<2>(M::mul(Rr, QX), M::mul(S1, PPP));
+    r.y = feb_widen<4>(M::mul_add_mul(Rr, QX, feb_neg<2>(S1), PPP));     // 4*10 + 2*2
     r.x = X3;
     r.zz = M::mul(M::mul(a.zz, b.zz), PP);
     r.zzz = M::mul(M::mul(a.zzz, b.zzz), PPP);

@@ -154,6 +154,12 @@ struct bp_ctx {
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     hipEvent_t ev[8] = {};
+    hipEvent_t ev_acc[16] = {};         // start / end of each window group's accumulate launch
+    hipEvent_t ev_sync[2] = {};         // fork / join of the auxiliary stream (no timing)
+    hipStream_t aux_stream = nullptr;   // second front stream of the window-group pipeline (bp_capi.hip: msm_windows)
+    hipStream_t tail_stream[8] = {};    // one per window group: combine / bucket reduce / window sums beside the next accumulates
+    hipEvent_t ev_tail[8] = {};
+    int last_groups = 0;
     bool ev_ready = false;
     float last_ms[8] = {};
     int last_ms_n = 0;

@@ -54,6 +54,7 @@ struct WinTab {
     uint8_t fbits[kMaxWindows];        // fine bits of a bucket id: min(8, cw - 1); the rest are the coarse bin
     uint16_t hoff[kMaxWindows + 1];    // first coarse-bin row of window w in the tile histogram (hoff[W] = rows)
     uint16_t rboff[kMaxWindows + 1];   // first block of window w in the (compact, 1-D) grid of k_bucket_reduce
+    uint8_t mw[kMaxWindows];           // buckets per reduce thread in window w (the last window group uses a shorter chain)
     ScalarWords bias;   // H = sum_w (2^(cw-1) - 1) 2^off[w]
 };
 constexpr int kRecPerWin = 1;          // tail records per window handed to the host (record r carries weight 2^rpos[r], bp_capi.hip)
@@ -124,9 +125,9 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
 // grid = (ntiles, W).  tile_off = scanned tile_hist.  Writes (code, point index) pairs grouped by coarse bin.
 static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab, uint32_t ntiles,
                                                                  const uint32_t* __restrict__ tile_off, uint16_t* __restrict__ tmp_code,
-                                                                 uint32_t* __restrict__ tmp_idx) {
+                                                                 uint32_t* __restrict__ tmp_idx, int w0) {
     __shared__ uint32_t lcur[128];
-    const int w = blockIdx.y;
+    const int w = w0 + (int)blockIdx.y;
     const int c = tab.cw[w], fb = tab.fbits[w];
     const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
     for (uint32_t k = threadIdx.x; k < nbins; k += kBlock) lcur[k] = tile_off[(size_t)(tab.hoff[w] + k) * ntiles + blockIdx.x];
@@ -152,9 +153,9 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
 // then placement.  Writes start[g] / end[g] for its 2^fbits buckets and idx[] (point index + sign bit).
 static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint16_t* __restrict__ tmp_code, const uint32_t* __restrict__ tmp_idx, WinTab tab,
                                                              uint32_t ntiles, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ total,
-                                                             uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx) {
+                                                             uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx, int w0) {
     __shared__ uint32_t lh[kBlock], lscan[kBlock / 64];
-    const int w = blockIdx.y;
+    const int w = w0 + (int)blockIdx.y;
     const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
     if (blockIdx.x >= nbins) return;
     const int c = tab.cw[w], fb = tab.fbits[w];
@@ -470,12 +471,13 @@ __device__ __forceinline__ XyzzLazy<C> xyzz_mul_small(uint32_t k, const XyzzLazy
 // per SIMD running this chain is the fastest form measured.)
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
-                                                          const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t m,
+                                                          const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t blk0,
                                                           XyzzPacked<C>* __restrict__ partial) {
     __shared__ XyzzPacked<C> lds[kBlock];
+    const uint32_t bid = blk0 + blockIdx.x;          // block id in the all-windows grid (a window group launches its own slice)
     uint32_t w = 0;
-    while (w + 1 < (uint32_t)tab.W && tab.rboff[w + 1] <= blockIdx.x) w++;   // uniform scan, W <= 256
-    const uint32_t bx = blockIdx.x - tab.rboff[w];
+    while (w + 1 < (uint32_t)tab.W && tab.rboff[w + 1] <= bid) w++;   // uniform scan, W <= 256
+    const uint32_t bx = bid - tab.rboff[w], m = tab.mw[w];
     uint32_t B = tab.boff[w + 1] - tab.boff[w];
     uint32_t t = bx * kBlock + threadIdx.x;
     uint32_t T = (B + m - 1) / m;
@@ -498,14 +500,14 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
     }
     uint32_t live = T - bx * kBlock;
     mine = block_tree_sum<C>(mine, lds, live < (uint32_t)kBlock ? (int)live : kBlock);
-    if (threadIdx.x == 0) partial[blockIdx.x] = xyzz_lazy_pack(mine);
+    if (threadIdx.x == 0) partial[bid] = xyzz_lazy_pack(mine);
 }
 
-// grid = W blocks: window_sum[w] = sum of partial[rboff[w] .. rboff[w+1])
+// grid = windows of the group: window_sum[w] = sum of partial[rboff[w] .. rboff[w+1])
 template <class C>
-__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, WinTab tab, XyzzPacked<C>* __restrict__ window_sum) {
+__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, WinTab tab, XyzzPacked<C>* __restrict__ window_sum, int w0) {
     __shared__ XyzzPacked<C> lds[kBlock];
-    uint32_t w = blockIdx.x;
+    uint32_t w = (uint32_t)w0 + blockIdx.x;
     const uint32_t first = tab.rboff[w], per_window = tab.rboff[w + 1] - first;
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
     for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(partial[first + j]));
