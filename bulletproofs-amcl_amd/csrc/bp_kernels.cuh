@@ -59,7 +59,7 @@ struct WinTab {
 };
 constexpr int kRecPerWin = 1;          // tail records per window handed to the host (record r carries weight 2^rpos[r], bp_capi.hip)
 
-constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane)
+constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane); larger MSMs use multiples (tile argument)
 constexpr int kMaxBinRows = 4096;      // sum over windows of coarse bins (c = 16: 16 x 128 per scalar set)
 
 // Signed-digit recoding without a serial carry: with k' = k + H, the raw cw-bit window w of k' equals
@@ -90,14 +90,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t
 // (The first version -- global-atomic histogram + global random scatter -- took 0.63 + 1.48 ms at n = 2^20 with 1.0 GB
 // of WRITE_SIZE for 64 MB of useful output: profiles/r01_bench_n1_pmc_hbm.json.)
 static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords* __restrict__ scalars, const ScalarWords* __restrict__ scalars2, size_t n,
-                                                             WinTab tab, uint32_t ntiles, uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
+                                                             WinTab tab, uint32_t ntiles, uint32_t tile, uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
     __shared__ uint32_t lh[kMaxBinRows];
     const uint32_t rows = tab.hoff[tab.W];
     for (uint32_t k = threadIdx.x; k < rows; k += kBlock) lh[k] = 0;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * kTile;
+    size_t base = (size_t)blockIdx.x * tile;
 #pragma unroll 1
-    for (int e = 0; e < kTile / kBlock; e++) {
+    for (uint32_t e = 0; e < tile / kBlock; e++) {
         size_t i = base + (size_t)e * kBlock + threadIdx.x;
         if (i < n) {
             const int wps = tab.W / tab.nsets;   // windows per scalar set (same geometry for every set)
@@ -125,16 +125,16 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
 // grid = (ntiles, W).  tile_off = scanned tile_hist.  Writes (code, point index) pairs grouped by coarse bin.
 static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab, uint32_t ntiles,
                                                                  const uint32_t* __restrict__ tile_off, uint16_t* __restrict__ tmp_code,
-                                                                 uint32_t* __restrict__ tmp_idx, int w0) {
+                                                                 uint32_t* __restrict__ tmp_idx, int w0, uint32_t tile) {
     __shared__ uint32_t lcur[128];
     const int w = w0 + (int)blockIdx.y;
     const int c = tab.cw[w], fb = tab.fbits[w];
     const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
     for (uint32_t k = threadIdx.x; k < nbins; k += kBlock) lcur[k] = tile_off[(size_t)(tab.hoff[w] + k) * ntiles + blockIdx.x];
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * kTile;
-#pragma unroll
-    for (int e = 0; e < kTile / kBlock; e++) {
+    size_t base = (size_t)blockIdx.x * tile;
+#pragma unroll 4
+    for (uint32_t e = 0; e < tile / kBlock; e++) {
         size_t i = base + (size_t)e * kBlock + threadIdx.x;
         if (i < n) {
             uint32_t raw = code[(size_t)w * n + i];
