@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ACC_KERNEL_PREFIX = "bp::k_accumulate<bp::Bls381"   # dominant kernel as rocprofv3 names it
+ACC_KERNEL_PREFIX = "k_accumulate<bp::Bls381"   # dominant kernel as rocprofv3 names it (void bp::k_accumulate<bp::Bls381, 2>(...))
 
 
 def random_scalars(r, bits, n, seed):
@@ -247,7 +247,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r02_bench_n1_pmc_hbm.json")
         if args.curve == "bls12_381" and args.lg_n == 20 and not args.strong and os.path.exists(pmc):
             pj = json.load(open(pmc))
-            k = next((v for name, v in pj.get("kernels", {}).items() if name.startswith(ACC_KERNEL_PREFIX)), {})
+            k = next((v for name, v in pj.get("kernels", {}).items() if ACC_KERNEL_PREFIX in name), {})
             if "FETCH_SIZE_KiB_avg" in k and "WRITE_SIZE_KiB_avg" in k:
                 traffic = int((k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
                 traffic_note = "stored profile profiles/r02_bench_n1_pmc_hbm.json (%s): raw FETCH_SIZE + WRITE_SIZE per launch" % pj.get("taken", "?")
