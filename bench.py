@@ -259,16 +259,19 @@ def main():
                         "kernel_ms": round(avg * 1e3, 4), "algorithmic_bytes_per_launch": n * unit_bytes,
                         "pipeline_GBs": round(n * unit_bytes / (float(np.mean(dev_ms)) * 1e-3) / 1e9, 2)}
             # The kernel is integer-ALU bound, so the HBM fraction says little about it.  Beside it: the rate of mixed additions
-            # against (a) the instruction-ISSUE ceiling -- a mixed addition is 8 products + 2 squares = 8 x 351 + 2 x 273
-            # multiply-class instructions (v_mad_u64_u32 / v_mul_lo) at the measured 4.5 cycles per wave64 instruction per SIMD,
-            # 1024 SIMDs at 2.4 GHz, nothing else counted -- and (b) this library's own multiplier loop (microbench/fpmul_rate.hip).
+            # against (a) the instruction-ISSUE ceiling -- the kernel's mixed addition is 6 products + 2 squares + one two-product /
+            # one-reduction form (bp_curve.cuh: xyzz_lazy_add_aff) = 6 x 351 + 2 x 273 + 520 = 3172 multiply-class instructions
+            # (v_mad_u64_u32 / v_mul_lo) at the measured 4.5 cycles per wave64 instruction per SIMD, 1024 SIMDs at 2.4 GHz, nothing
+            # else counted -- and (b) the multiply-instruction rate this library's own multiplier loop sustains
+            # (microbench/fpmul_rate.hip: 6.6e10 products/s x 351).
             if args.curve == "bls12_381":
                 adds = n * n_windows / avg
-                issue_peak = 1024 * 64 * 2.4e9 / ((8 * 351 + 2 * 273) * 4.5)
+                mul_instr = 6 * 351 + 2 * 273 + 520
+                issue_peak = 1024 * 64 * 2.4e9 / (mul_instr * 4.5)
                 roofline["alu"] = {"achieved": round(adds, 0), "unit": "mixed additions/s", "peak": round(issue_peak, 0), "frac": round(adds / issue_peak, 4),
-                                   "how": "n * windows additions / kernel time; peak = issue limit of the multiply instructions alone (8*351 + 2*273 per addition, "
+                                   "how": "n * windows additions / kernel time; peak = issue limit of the multiply instructions alone (6*351 + 2*273 + 520 = 3172 per addition, "
                                           "4.5 cyc per wave64 instruction, 1024 SIMDs, 2.4 GHz)",
-                                   "vs_own_multiplier_microbench": round(adds * 10 / 6.6e10, 4)}
+                                   "vs_own_multiplier_microbench": round(adds * mul_instr / (6.6e10 * 351), 4)}
         out = {
             "metric": "BLS12-381 G1 scalar-muls/s at n=2^20 MSM" if (args.curve == "bls12_381" and args.lg_n == 20 and not args.strong) else
                       "%s G1 scalar-muls/s at n=2^%d MSM%s" % (args.curve, args.lg_n, " (total, strong scaling)" if args.strong else ""),

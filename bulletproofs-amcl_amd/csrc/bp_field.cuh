@@ -606,7 +606,8 @@ template <class P> BP_HD_NOINLINE LimbsV<P> feb_sqr_outlined(LimbsV<P> a) {
     return o;
 }
 
-// multiplier policies for the curve formulas: same bounds, same results; Inline for the accumulate loop, Call elsewhere
+// multiplier policies for the curve formulas: same bounds, same results.  The library uses MulInline everywhere; MulCall (one
+// out-of-line multiplier, ~30 % slower per dependent step, far less code) exists for microbench/point_latency.hip's comparison
 struct MulInline {
     template <class P, int B1, int B2> static BP_HD FeB<P, 2> mul(const FeB<P, B1>& a, const FeB<P, B2>& b) { return feb_mul(a, b); }
     template <class P, int B1> static BP_HD FeB<P, 2> sqr(const FeB<P, B1>& a) { return feb_sqr(a); }
@@ -633,12 +634,7 @@ struct MulCall {
         return r;
     }
     template <class P, int B1, int B2, int B3, int B4>
-    static BP_HD FeB<P, 2> mul_add_mul(const FeB<P, B1>& a1, const FeB<P, B2>& b1, const FeB<P, B3>& a2, const FeB<P, B4>& b2) {
-        FeB<P, 4> s = feb_add(mul(a1, b1), mul(a2, b2));
-        FeB<P, 2> r;                                          // (value < 4p here; only the accumulate loop cares, and it uses MulInline)
-        for (int i = 0; i < P::NL; i++) r.v[i] = s.v[i];
-        return r;
-    }
+    static BP_HD FeB<P, 2> mul_add_mul(const FeB<P, B1>& a1, const FeB<P, B2>& b1, const FeB<P, B3>& a2, const FeB<P, B4>& b2) { return feb_mul_add_mul(a1, b1, a2, b2); }   // no out-of-line form: used once per addition
 };
 
 }  // namespace bp

@@ -15,7 +15,7 @@ bp = G.load_package()
 def rand_scalars(ctx, n, seed):
     rng = np.random.default_rng(seed)
     a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-    a[:, 31] &= 0x1F            # < 2^253 < r for both curves (uploads reject scalars >= r)
+    a[:, 31] &= 0x3F if ctx.curve == 0 else 0x1F     # < 2^254 < r (BLS12-381) / < 2^253 < r (BN254): uploads reject scalars >= r
     return a.tobytes()
 
 
