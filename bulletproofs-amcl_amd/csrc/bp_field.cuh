@@ -220,6 +220,25 @@ template <class P> BP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
 template <class P> BP_HD Fe<P> fe_neg(const Fe<P>& a) { return fe_sub<P>(fe_zero<P>(), a); }
 template <class P> BP_HD Fe<P> fe_dbl(const Fe<P>& a) { return fe_add<P>(a, a); }
 
+// The column sums are written as chains  acc = a*b + acc  starting from the carry of the previous column, which is exactly one
+// v_mad_u64_u32 per product.  Left alone, the optimiser re-associates each column into "products first, carry last" and pays
+// one or two extra 64-bit additions per column (44 half-rate instructions per product).  Showing every partial sum to an
+// empty volatile asm gives it a second use, which makes it a leaf for the re-association and pins the order; nothing is
+// emitted.  Used in the LAZY multipliers only (the MSM kernels): in the big strict-arithmetic kernels (hash to G1) the pinned
+// order raises register pressure until the allocator spills (k_clear_cofactor: 1781 scratch loads, 3x slower).
+// (An asm that also DEFINES the accumulator works too but draws an s_nop per step from the gfx940+ hazard
+// recogniser -- "assume inline asm has a dst forwarding hazard" -- which costs lone waves more than the additions saved.)
+// The reduction pass adds the limb t[k] of the double-length product into its column.  As a plain 64-bit addition that is a
+// v_mov (zero high word) + v_lshl_add_u64; as  t[k] * 1 + acc  with a 1 the optimiser cannot see through it is one more
+// v_mad_u64_u32 on the same chain (BP_OPAQUE_ONE: a scalar register holding 1).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_KEEP_ORDER(acc) asm volatile("" ::"v"(acc))
+#define BP_OPAQUE_ONE(one) asm("" : "+s"(one))
+#else
+#define BP_KEEP_ORDER(acc) ((void)0)
+#define BP_OPAQUE_ONE(one) ((void)0)
+#endif
+
 // Montgomery reduction of 2*NL normalised limbs t (value < p * R) -> t / R mod p, product scanning.
 template <class P> BP_HD Fe<P> fe_mont_reduce(const uint32_t* t) {
     constexpr int N = P::NL;
@@ -393,28 +412,30 @@ template <class P, int B1, int B2> BP_HD FeB<P, 2> feb_mul(const FeB<P, B1>& a, 
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; k++) {
 #pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; BP_KEEP_ORDER(acc); }
         t[k] = (uint32_t)acc & LMASK;
         acc >>= LB;
     }
     t[2 * N - 1] = (uint32_t)acc;
     uint32_t m[N];
+    uint32_t one = 1;
+    BP_OPAQUE_ONE(one);
     acc = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        acc += t[k];
+        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
         m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
-        acc += (uint64_t)m[k] * P::C.mod[0];
+        { acc += (uint64_t)m[k] * P::C.mod[0]; BP_KEEP_ORDER(acc); }
         acc >>= LB;
     }
     FeB<P, 2> r;
 #pragma unroll
     for (int k = N; k < 2 * N; k++) {
-        acc += t[k];
+        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
 #pragma unroll
-        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
         r.v[k - N] = (uint32_t)acc & LMASK;
         acc >>= LB;
     }
@@ -432,7 +453,7 @@ BP_HD FeB<P, 2> feb_mul_add_mul(const FeB<P, B1>& a1, const FeB<P, B2>& b1, cons
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; k++) {
 #pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) acc += (uint64_t)a1.v[i] * b1.v[k - i];
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) { acc += (uint64_t)a1.v[i] * b1.v[k - i]; BP_KEEP_ORDER(acc); }
         t[k] = (uint32_t)acc & LMASK;
         acc >>= LB;
     }
@@ -441,28 +462,30 @@ BP_HD FeB<P, 2> feb_mul_add_mul(const FeB<P, B1>& a1, const FeB<P, B2>& b1, cons
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; k++) {
 #pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) acc += (uint64_t)a2.v[i] * b2.v[k - i];
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) { acc += (uint64_t)a2.v[i] * b2.v[k - i]; BP_KEEP_ORDER(acc); }
         t[k] += (uint32_t)acc & LMASK;           // < 2^31: the reduction below adds t[k] into a 64-bit column
         acc >>= LB;
     }
     t[2 * N - 1] += (uint32_t)acc;
     uint32_t m[N];
+    uint32_t one = 1;
+    BP_OPAQUE_ONE(one);
     acc = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        acc += t[k];
+        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
         m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
-        acc += (uint64_t)m[k] * P::C.mod[0];
+        { acc += (uint64_t)m[k] * P::C.mod[0]; BP_KEEP_ORDER(acc); }
         acc >>= LB;
     }
     FeB<P, 2> r;
 #pragma unroll
     for (int k = N; k < 2 * N; k++) {
-        acc += t[k];
+        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
 #pragma unroll
-        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
         r.v[k - N] = (uint32_t)acc & LMASK;
         acc >>= LB;
     }
@@ -495,29 +518,31 @@ template <class P, int B1> BP_HD FeB<P, 2> feb_sqr(const FeB<P, B1>& a) {
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; k++) {
 #pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; BP_KEEP_ORDER(acc); }
+        if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; BP_KEEP_ORDER(acc); }
         t[k] = (uint32_t)acc & LMASK;
         acc >>= LB;
     }
     t[2 * N - 1] = (uint32_t)acc;
     uint32_t m[N];
+    uint32_t one = 1;
+    BP_OPAQUE_ONE(one);
     acc = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        acc += t[k];
+        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
         m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
-        acc += (uint64_t)m[k] * P::C.mod[0];
+        { acc += (uint64_t)m[k] * P::C.mod[0]; BP_KEEP_ORDER(acc); }
         acc >>= LB;
     }
     FeB<P, 2> r;
 #pragma unroll
     for (int k = N; k < 2 * N; k++) {
-        acc += t[k];
+        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
 #pragma unroll
-        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::C.mod[k - i];
+        for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
         r.v[k - N] = (uint32_t)acc & LMASK;
         acc >>= LB;
     }
