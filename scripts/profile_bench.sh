@@ -33,10 +33,12 @@ def load(name):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
-try:
-    rev = subprocess.check_output(["git", "-C", os.path.dirname(out), "rev-parse", "--short", "HEAD"], text=True).strip()
-except Exception:
-    rev = "worktree"
+rev = os.environ.get("BP_GIT_REV", "")
+if not rev:
+    try:
+        rev = subprocess.check_output(["git", "-C", os.path.dirname(out), "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        rev = "worktree"
 taken = time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()) + ", tree " + rev
 hbm = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify  (one pass per counter)",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3, per-launch averages, RAW (the guide's x2 read-side correction is calibrated for wide "
