@@ -136,10 +136,34 @@ public:
         check(bp_g1vec_from_msg_hash(ctx.handle(), reinterpret_cast<const uint8_t*>(all.data()), offs.data(), messages.size(), &h), "bp_g1vec_from_msg_hash");
         return G1Vector(ctx, h);
     }
+    // this build's compressed wire form (tag || X big-endian, bp_g1_compressed_bytes per point); invalid encodings -> ArgError
+    static G1Vector from_compressed(Context& ctx, const Bytes& compressed) {
+        bp_g1vec* h = nullptr;
+        check(bp_g1vec_decompress(ctx.handle(), compressed.data(), compressed.size() / bp_g1_compressed_bytes(ctx.curve()), &h), "bp_g1vec_decompress");
+        return G1Vector(ctx, h);
+    }
+    Bytes to_compressed() const {
+        Bytes out(len() * bp_g1_compressed_bytes(ctx_->curve()));
+        check(bp_g1vec_compress(ctx_->handle(), h_, 0, len(), out.data()), "bp_g1vec_compress");
+        return out;
+    }
     size_t len() const { return bp_g1vec_len(h_); }
     Bytes to_bytes() const {
         Bytes out(len() * ctx_->point_bytes());
         check(bp_g1vec_download(ctx_->handle(), h_, 0, len(), BP_FMT_LE, out.data()), "bp_g1vec_download");
+        return out;
+    }
+    // multi_scalar_mul_var_time over index-range shards that live in several contexts (one per device; several contexts on one
+    // device work too): every shard's device stage runs concurrently, one host fold (bp_msm_g1_multi)
+    static Bytes multi_scalar_mul_var_time_sharded(const std::vector<Context*>& ctxs, const std::vector<const G1Vector*>& points,
+                                                   const std::vector<const FieldElementVector*>& scalars) {
+        if (ctxs.empty() || ctxs.size() != points.size() || ctxs.size() != scalars.size()) throw ValueError("multi_scalar_mul_var_time_sharded", BP_ERR_LENGTH);
+        std::vector<bp_ctx*> c;
+        std::vector<const bp_g1vec*> p;
+        std::vector<const bp_frvec*> k;
+        for (size_t i = 0; i < ctxs.size(); i++) { c.push_back(ctxs[i]->handle()); p.push_back(points[i]->handle()); k.push_back(scalars[i]->handle()); }
+        Bytes out(ctxs[0]->point_bytes());
+        check(bp_msm_g1_multi(c.data(), p.data(), k.data(), c.size(), out.data()), "bp_msm_g1_multi");
         return out;
     }
     Bytes multi_scalar_mul_var_time(const FieldElementVector& scalars) const {
@@ -300,11 +324,24 @@ inline Bytes prove(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Ve
 }
 
 // Verifier::verify (verifier.rs:265-452): returns on success, throws VerificationError otherwise.
+// r_weight_le32: the verifier's random combination weight (verifier.rs:392); empty = drawn inside the library (the reference's behaviour).
 inline void verify(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Vector& G, const G1Vector& H, const Bytes& g, const Bytes& h, const Bytes& V,
-                   const Bytes& proof, const Bytes& r_weight_le32) {
+                   const Bytes& proof, const Bytes& r_weight_le32 = Bytes()) {
     check(bp_r1cs_verify(ctx.handle(), t.handle(), plan.handle(), G.handle(), H.handle(), g.data(), h.data(), V.empty() ? nullptr : V.data(), plan.n(),
-                         V.size() / ctx.point_bytes(), proof.data(), proof.size(), r_weight_le32.data()),
+                         V.size() / ctx.point_bytes(), proof.data(), proof.size(), r_weight_le32.empty() ? nullptr : r_weight_le32.data()),
           "bp_r1cs_verify");
+}
+
+// serde of R1CSProof (src/r1cs/proof.rs:24) in this build's compressed point form; a bad encoding -> VerificationError
+inline Bytes compress_proof(Context& ctx, size_t n_gates, const Bytes& proof) {
+    Bytes out(bp_r1cs_proof_compressed_bytes(ctx.curve(), n_gates));
+    check(bp_r1cs_proof_compress(ctx.handle(), n_gates, proof.data(), proof.size(), out.data(), out.size()), "bp_r1cs_proof_compress");
+    return out;
+}
+inline Bytes decompress_proof(Context& ctx, size_t n_gates, const Bytes& compressed) {
+    Bytes out(bp_r1cs_proof_bytes(ctx.curve(), n_gates));
+    check(bp_r1cs_proof_decompress(ctx.handle(), n_gates, compressed.data(), compressed.size(), out.data(), out.size()), "bp_r1cs_proof_decompress");
+    return out;
 }
 
 }  // namespace r1cs

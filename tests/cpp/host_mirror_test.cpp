@@ -96,6 +96,13 @@ static int gpu_mode(int curve) {
             bp::r1cs::start_transcript(ctx, tv, V);
             bp::r1cs::verify(ctx, tv, plan, GG, HH, gq, hq, V, rproof, scalar(0x5eed5eed));
         }
+        {   // library-drawn weight, and the proof through its compressed wire form
+            bp::Bytes wire = bp::r1cs::compress_proof(ctx, 2, rproof);
+            if (wire.size() >= rproof.size() || bp::r1cs::decompress_proof(ctx, 2, wire) != rproof) { printf("compressed proof round trip failed\n"); return 1; }
+            bp::Transcript tv("cpp r1cs");
+            bp::r1cs::start_transcript(ctx, tv, V);
+            bp::r1cs::verify(ctx, tv, plan, GG, HH, gq, hq, V, bp::r1cs::decompress_proof(ctx, 2, wire));
+        }
         try {
             bp::Bytes badp = rproof;
             badp[11 * ctx.point_bytes()] ^= 1;                   // t_x
@@ -115,6 +122,15 @@ static int gpu_mode(int curve) {
             bp::r1cs::verify(ctx, tv, plan, GG, HH, gq, hq, V16, p2, scalar(77));
             printf("unsatisfied circuit accepted\n"); return 1;
         } catch (const bp::VerificationError&) {}
+    }
+    {   // compressed generators round-trip; the MSM over two index-range shards held by two contexts equals the single-context MSM
+        if (bp::G1Vector::from_compressed(ctx, Gh.to_compressed()).to_bytes() != Gh.to_bytes()) { printf("compressed points differ\n"); return 1; }
+        bp::Context ctx2(curve, 0);
+        const size_t tot = pts2.len(), half = tot / 2, pb = ctx.point_bytes();
+        bp::Bytes pb_all = pts2.to_bytes(), sc_all = sc.to_bytes();
+        bp::G1Vector p_lo(ctx, bp::Bytes(pb_all.begin(), pb_all.begin() + half * pb)), p_hi(ctx2, bp::Bytes(pb_all.begin() + half * pb, pb_all.end()));
+        bp::FieldElementVector s_lo(ctx, bp::Bytes(sc_all.begin(), sc_all.begin() + half * 32)), s_hi(ctx2, bp::Bytes(sc_all.begin() + half * 32, sc_all.end()));
+        if (bp::G1Vector::multi_scalar_mul_var_time_sharded({&ctx, &ctx2}, {&p_lo, &p_hi}, {&s_lo, &s_hi}) != P2) { printf("sharded MSM differs\n"); return 1; }
     }
     printf("cpp gpu ok curve=%d a=%s\n", curve, hex(proof.a).c_str());
     return 0;

@@ -26,7 +26,13 @@ def test_curve_constants(golden, name):
     assert O.g1_add(cid, hx(g["G_rm1"]), G) == bytes(len(G))          # r*G = O
     assert O.g1_to_amcl(cid, G) == hx(g["G_amcl"])
     assert O.g1_to_amcl(cid, bytes(len(G))) == hx(g["identity_amcl"])
-    if name == "bls12_381":   # published 2G
+    if name == "bls12_381":   # public constants of the curve (IETF pairing-friendly-curves draft / zkcrypto), then the published 2G
+        assert int(g["p"], 16) == 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+        assert int(g["r"], 16) == 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+        assert int(g["gx"], 16) == 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+        assert int(g["gy"], 16) == 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+        z = -0xd201000000010000            # the BLS parameter: r = z^4 - z^2 + 1, p = (z - 1)^2 r / 3 + z, cofactor = (z - 1)^2 / 3
+        assert int(g["r"], 16) == z**4 - z**2 + 1 and int(g["p"], 16) == (z - 1) ** 2 * int(g["r"], 16) // 3 + z
         x2 = int("0572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e", 16)
         assert O.g1_add(cid, G, G)[:48] == x2.to_bytes(48, "little")
 
@@ -161,6 +167,14 @@ def test_shake256_matches_hashlib_and_golden(golden):
         out = ctypes.create_string_buffer(200)
         L.orc_shake256(msg, ctypes.c_size_t(n), out, ctypes.c_size_t(200))   # squeeze past one rate block
         assert out.raw == hashlib.shake_256(msg).digest(200)
+    # long message / long output (hundreds of absorb and squeeze blocks), and the two public FIPS 202 answers for the empty message
+    msg = bytes((i * i + 3 * i) & 0xFF for i in range(100003))
+    out = ctypes.create_string_buffer(10007)
+    L.orc_shake256(msg, ctypes.c_size_t(len(msg)), out, ctypes.c_size_t(10007))
+    assert out.raw == hashlib.shake_256(msg).digest(10007)
+    out = ctypes.create_string_buffer(32)
+    L.orc_shake256(b"", ctypes.c_size_t(0), out, ctypes.c_size_t(32))
+    assert out.raw.hex() == "46b9dd2b0ba88d13233b3feb743eeb243fcd52ea62b81b82b50c27646ed5762f"   # SHAKE256(""), FIPS 202 / NIST example
 
 
 @pytest.mark.parametrize("name", ["bls12_381", "bn254"])
