@@ -671,8 +671,10 @@ int bp_ctx_create(int curve_id, int device_ordinal, bp_ctx** out) {
 
 int bp_ctx_destroy(bp_ctx* ctx) {
     if (!ctx) return BP_OK;
+    for (auto& h : ctx->helper) { if (h) bp_ctx_destroy(h); h = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->fixed_base_table.release();
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_code, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
                       &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags}) b->release();
@@ -688,6 +690,28 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+    return BP_OK;
+}
+
+// Sibling context k of `ctx` (same curve, device and options; its own stream and workspace), created on first use and destroyed
+// with `ctx`.  bp_internal_fork makes the sibling's stream wait for everything queued on ctx->stream so far, so vectors built on
+// the parent can be consumed there.  Used for independent MSMs in flight from one host thread (bp_capi_r1cs.hip).
+bp_ctx* bp_internal_helper(bp_ctx* ctx, int k) {
+    if (!ctx || k < 0 || k > 1) return nullptr;
+    if (!ctx->helper[k]) {
+        bp_ctx* h = nullptr;
+        if (bp_ctx_create(ctx->curve, ctx->device, &h) != BP_OK) return nullptr;
+        ctx->helper[k] = h;
+    }
+    bp_ctx* h = ctx->helper[k];
+    h->c_override = ctx->c_override;
+    h->device_tail = ctx->device_tail;
+    return h;
+}
+int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling) {
+    if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(sibling->stream, ctx->ev_fork, 0));
     return BP_OK;
 }
 

@@ -81,8 +81,8 @@ struct R1cs {
         return BP_OK;
     }
 
-    // <a, G> + <b, H> + c h     (commit_to_field_element_vectors, prover.rs:346-361); b == nullptr: <a, G> + c h
-    static int commit_vectors(bp_ctx* ctx, Temps& T, const bp_g1vec* GHh, size_t n, const bp_frvec* a, const bp_frvec* b, const Fe<F>& c, uint8_t* out_le) {
+    // scalars [a | b | c] of  <a, G> + <b, H> + c h  (commit_to_field_element_vectors, prover.rs:346-361); b == nullptr: <a, G> + c h
+    static int commit_scalars(bp_ctx* ctx, Temps& T, size_t n, const bp_frvec* a, const bp_frvec* b, const Fe<F>& c, bp_frvec** out) {
         bp_frvec *sc = nullptr, *one = nullptr;
         RC(bp_frvec_alloc(ctx, 2 * n + 1, &sc));
         T.keep(sc);
@@ -92,7 +92,29 @@ struct R1cs {
         fr_out<F>(c, cle.data());
         RC(upload_scalars(ctx, T, cle, &one));
         RC(bp_frvec_copy(ctx, sc, 2 * n, one, 0, 1));
-        return bp_msm_g1(ctx, GHh, sc, out_le);
+        *out = sc;
+        return BP_OK;
+    }
+    // k <= 3 independent commitments over the same [G | H | h]: all in flight at once, on the context and its two siblings (the
+    // latency-bound bucket reduce and host tail of one hide behind the accumulate of the others).  Every MSM that was begun is
+    // ended before returning, whatever failed, because the vectors in T are released on return.
+    static int commit_vectors_concurrent(bp_ctx* ctx, const bp_g1vec* GHh, bp_frvec* const sc[], uint8_t* const out_le[], int k) {
+        bp_ctx* ex[3] = {ctx, bp_internal_helper(ctx, 0), bp_internal_helper(ctx, 1)};
+        if (k > 3 || !ex[1] || !ex[2]) { for (int i = 0; i < k; i++) RC(bp_msm_g1(ctx, GHh, sc[i], out_le[i])); return BP_OK; }
+        int rc = BP_OK, begun = 0;
+        for (int i = 0; i < k && rc == BP_OK; i++) {
+            if (i > 0) rc = bp_internal_fork(ctx, ex[i]);
+            if (rc == BP_OK) rc = bp_msm_g1_begin(ex[i], GHh, sc[i]);
+            if (rc == BP_OK) begun++;
+        }
+        // the three host tails (~0.13 ms each) on the siblings' helper threads beside this one
+        int r_end[3] = {BP_OK, BP_OK, BP_OK};
+        bool queued[3] = {false, false, false};
+        for (int i = 1; i < begun; i++) queued[i] = ex[i]->worker.submit([&, i]() { r_end[i] = bp_msm_g1_end(ex[i], out_le[i]); });
+        for (int i = 0; i < begun; i++) if (!queued[i]) r_end[i] = bp_msm_g1_end(ex[i], out_le[i]);
+        for (int i = 1; i < begun; i++) if (queued[i]) ex[i]->worker.wait();
+        for (int i = 0; i < begun; i++) if (rc == BP_OK) rc = r_end[i];
+        return rc;
     }
 
     static Fe<F> challenge(bp_transcript* t, int curve, const char* label) {
@@ -122,9 +144,14 @@ struct R1cs {
         RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // prover.rs:328
         bp_g1vec* GHh = nullptr;
         RC(cat_GHh(ctx, T, G, H, h_le, n, &GHh));
-        RC(commit_vectors(ctx, T, GHh, n, aL, aR, i_bl, P + 0 * pb));                                          // A_I1  :346-354
-        RC(commit_vectors(ctx, T, GHh, n, aO, nullptr, o_bl, P + 1 * pb));                                     // A_O1  :357
-        RC(commit_vectors(ctx, T, GHh, n, sL, sR, s_bl, P + 2 * pb));                                          // S1    :360-361
+        {   // A_I1 (:346-354), A_O1 (:357), S1 (:360-361): independent of each other and of the transcript, computed concurrently
+            bp_frvec* sc3[3] = {nullptr, nullptr, nullptr};
+            RC(commit_scalars(ctx, T, n, aL, aR, i_bl, &sc3[0]));
+            RC(commit_scalars(ctx, T, n, aO, nullptr, o_bl, &sc3[1]));
+            RC(commit_scalars(ctx, T, n, sL, sR, s_bl, &sc3[2]));
+            uint8_t* out3[3] = {P + 0 * pb, P + 1 * pb, P + 2 * pb};
+            RC(commit_vectors_concurrent(ctx, GHh, sc3, out3, 3));
+        }
         RC(bp_transcript_commit_point(t, cv, "A_I1", P + 0 * pb));
         RC(bp_transcript_commit_point(t, cv, "A_O1", P + 1 * pb));
         RC(bp_transcript_commit_point(t, cv, "S1", P + 2 * pb));

@@ -165,6 +165,8 @@ struct bp_ctx {
     int last_ms_n = 0;
     DevPool* pool = nullptr;            // vectors and temporaries (see DevPool)
     HostWorker worker;
+    bp_ctx* helper[2] = {nullptr, nullptr};   // lazily created sibling contexts (own stream + workspace) for independent MSMs in flight
+    hipEvent_t ev_fork = nullptr;             // "everything queued on this context so far" for the siblings' streams
     DevBuf flags;                       // 64 B of device error flags (point / scalar validation)
     // geometry of the MSM queued by bp_msm_g1_begin (consumed by _end; bp_ctx_set_window_bits in between cannot disturb it)
     int pending_nrec = 0;
@@ -230,6 +232,9 @@ static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
 
 // MSM over raw resident device arrays (n > 0 or n == 0 -> identity); defined in bp_capi.hip.
 int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le);
+// sibling contexts for independent MSMs in flight (bp_capi.hip)
+extern "C" bp_ctx* bp_internal_helper(bp_ctx* ctx, int k);
+extern "C" int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling);
 // nnz = non-zero scalars per set if known (0: assume n)
 int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
                      size_t nnz);

@@ -540,6 +540,13 @@ class R1CSProver:
         self.curve, self.g, self.h, self.t = curve, g, h, transcript
         transcript.append_message(b"dom-sep", b"r1cs v1")            # r1cs_domain_sep, prover.rs:85, transcript.rs:35-37
         self.constraints, self.aL, self.aR, self.aO, self.v, self.v_blinding = [], [], [], [], [], []
+        self.deferred = []                                             # deferred_constraints, prover.rs:50-52
+
+    def specify_randomized_constraints(self, callback):                # Prover: prover.rs:665-672 (remember it for the second phase)
+        self.deferred.append(callback)
+
+    def challenge_scalar(self, label):                                 # RandomizingProver::challenge_scalar, prover.rs:759-763
+        return self.t.challenge_scalar(self.curve, label)
 
     def commit(self, v, v_blinding):                                   # prover.rs:118-127
         c = self.curve
@@ -578,6 +585,13 @@ class R1CSVerifier:
         self.curve, self.t = curve, transcript
         transcript.append_message(b"dom-sep", b"r1cs v1")
         self.constraints, self.V, self.num_vars = [], [], 0
+        self.deferred = []
+
+    def specify_randomized_constraints(self, callback):                # verifier.rs:508-515
+        self.deferred.append(callback)
+
+    def challenge_scalar(self, label):                                 # RandomizingVerifier::challenge_scalar, verifier.rs:596-600
+        return self.t.challenge_scalar(self.curve, label)
 
     def commit(self, V):
         self.V.append(V)
@@ -671,8 +685,9 @@ def _next_pow2(n):
 
 
 def r1cs_prove(prover, G, H, rand):
-    """Prover::prove, src/r1cs/prover.rs:322-593, for a system without deferred (second-phase) constraints.
-    rand: dict with i_blinding1, o_blinding1, s_blinding1, s_L1, s_R1 (lists of n), t_1_blinding, t_3_.., t_4_.., t_5_.., t_6_...
+    """Prover::prove, src/r1cs/prover.rs:322-593, with or without deferred (second-phase) constraints.
+    rand: dict with i_blinding1, o_blinding1, s_blinding1, s_L1, s_R1 (lists of n1), t_1_blinding, t_3_.., t_4_.., t_5_.., t_6_..;
+    a system with second-phase multipliers also needs i_blinding2, o_blinding2, s_blinding2, s_L2, s_R2 (lists of n2).
     Returns a dict holding the fields of R1CSProof (src/r1cs/proof.rs:24-58)."""
     c, t = prover.curve, prover.t
     r = c.r
@@ -691,14 +706,31 @@ def r1cs_prove(prover, G, H, rand):
     t.commit_point(c, b"A_I1", A_I1)
     t.commit_point(c, b"A_O1", A_O1)
     t.commit_point(c, b"S1", S1)                                                               # :364-366
-    t.append_message(b"dom-sep", b"r1cs-1phase")                                               # :369, :304-306 (no deferred constraints)
+    if not prover.deferred:                                                                    # create_randomized_constraints, :299-319
+        t.append_message(b"dom-sep", b"r1cs-1phase")
+    else:
+        t.append_message(b"dom-sep", b"r1cs-2phase")
+        callbacks, prover.deferred = prover.deferred, []
+        for cb in callbacks:
+            cb(prover)                                                                         # the callback sees a RandomizingProver
     n = len(prover.aL)
-    n2 = n - n1                                                                                # 0
+    n2 = n - n1
     padded_n = _next_pow2(n)
     pad = padded_n - n
     assert len(G) >= padded_n                                                                  # :381
-    i_b2 = o_b2 = s_b2 = 0                                                                     # :398-402
-    A_I2 = A_O2 = S2 = None                                                                    # :429 identity
+    if n2 > 0:                                                                                 # :385-431
+        i_b2, o_b2, s_b2 = rand["i_blinding2"], rand["o_blinding2"], rand["s_blinding2"]
+        sL2, sR2 = list(rand["s_L2"]), list(rand["s_R2"])
+        assert len(sL2) == n2 and len(sR2) == n2
+        G2, H2 = G[n1:n], H[n1:n]
+        A_I2 = c.add(c.add(c.msm(prover.aL[n1:], G2), c.msm(prover.aR[n1:], H2)), c.mul(i_b2, h))
+        A_O2 = c.add(c.msm(prover.aO[n1:], G2), c.mul(o_b2, h))
+        S2 = c.add(c.add(c.msm(sL2, G2), c.msm(sR2, H2)), c.mul(s_b2, h))
+    else:
+        i_b2 = o_b2 = s_b2 = 0                                                                 # :398-402
+        sL2, sR2 = [], []
+        A_I2 = A_O2 = S2 = None                                                                # :429 identity
+    sL1, sR1 = sL1 + sL2, sR1 + sR2                                                            # :466-468: s_L1.chain(s_L2), s_R1.chain(s_R2)
     t.commit_point(c, b"A_I2", A_I2)
     t.commit_point(c, b"A_O2", A_O2)
     t.commit_point(c, b"S2", S2)                                                               # :432-434
@@ -768,7 +800,13 @@ def r1cs_verifier_msm(verifier, proof, g, h, G, H, rnd):
     t.commit_point(c, b"A_I1", proof["A_I1"])
     t.commit_point(c, b"A_O1", proof["A_O1"])
     t.commit_point(c, b"S1", proof["S1"])                                                      # :282-284
-    t.append_message(b"dom-sep", b"r1cs-1phase")                                               # :287 (no deferred constraints)
+    if not verifier.deferred:                                                                  # create_randomized_constraints, :245-263
+        t.append_message(b"dom-sep", b"r1cs-1phase")
+    else:
+        t.append_message(b"dom-sep", b"r1cs-2phase")
+        callbacks, verifier.deferred = verifier.deferred, []
+        for cb in callbacks:
+            cb(verifier)
     n = verifier.num_vars
     n2 = n - n1
     padded_n = _next_pow2(n)
