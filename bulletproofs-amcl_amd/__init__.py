@@ -130,6 +130,11 @@ SYMBOLS = {
     "bp_r1cs_proof_bytes": (_SZ, [_I, _SZ]),
     "bp_r1cs_prove": (_I, [_P, _P, _P, _P, _P, _U8P, _U8P, _P, _P, _P, _P, _P, _P, _U8P, _U8P, _SZ]),
     "bp_r1cs_verify": (_I, [_P, _P, _P, _P, _P, _U8P, _U8P, _U8P, _SZ, _SZ, _U8P, _SZ, _U8P]),
+    "bp_r1cs_phase1_bytes": (_SZ, []),
+    "bp_r1cs_prove_begin": (_I, [_P, _P, _P, _P, _U8P, _SZ, _P, _P, _P, _P, _P, _U8P, _U8P, _SZ]),
+    "bp_r1cs_prove_finish": (_I, [_P, _P, _P, _P, _P, _U8P, _U8P, _U8P, _P, _P, _P, _P, _P, _P, _U8P, _U8P, _SZ]),
+    "bp_r1cs_verify_begin": (_I, [_P, _I, _SZ, _U8P, _SZ]),
+    "bp_r1cs_verify_finish": (_I, [_P, _P, _P, _P, _P, _U8P, _U8P, _U8P, _SZ, _SZ, _SZ, _U8P, _SZ, _U8P]),
     "bp_r1cs_prover_polys": (_I, [_P, _PP, _U8P, _PP]),
     "bp_r1cs_ipp_inputs": (_I, [_P, _P, _P, _U8P, _U8P, _SZ, _SZ, _PP]),
     "bp_r1cs_verifier_scalars": (_I, [_P, _P, _U8P, _U8P, _SZ, _SZ, _SZ, _P, _P, _P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _U8P, _PP, _PP]),
@@ -820,6 +825,42 @@ def r1cs_verify(ctx, transcript, plan, G, H, g_le, h_le, V_le, n, proof, r_le32=
     m = len(V_le) // ctx.point_bytes
     _check(lib().bp_r1cs_verify(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), bytes(V_le) or None, n, m, bytes(proof), len(proof),
                                 bytes(r_le32) if r_le32 is not None else None), "bp_r1cs_verify")
+
+
+def r1cs_prove_begin(ctx, transcript, G, H, h_le, m, a_L1, a_R1, a_O1, s_L1, s_R1, blindings3_le32):
+    """Prover::prove up to create_randomized_constraints (prover.rs:323-369) for a system with second-phase constraints: "m", A_I1, A_O1,
+    S1 and the 2-phase domain separator go onto the transcript; returns the opaque phase-1 bytes for r1cs_prove_finish.  The caller then
+    plays the deferred callbacks (transcript.challenge_scalar = RandomizedConstraintSystem::challenge_scalar).  Vectors may be None / empty
+    when there is no first-phase multiplier."""
+    size = lib().bp_r1cs_phase1_bytes()
+    out = ctypes.create_string_buffer(size)
+    hv = lambda v: v.h if v is not None and len(v) else None
+    _check(lib().bp_r1cs_prove_begin(ctx.h, transcript.h, G.h, H.h, bytes(h_le), m, hv(a_L1), hv(a_R1), hv(a_O1), hv(s_L1), hv(s_R1),
+                                     bytes(blindings3_le32), out, size), "bp_r1cs_prove_begin")
+    return out.raw
+
+
+def r1cs_prove_finish(ctx, transcript, plan, G, H, g_le, h_le, phase1, a_L, a_R, a_O, v_blinding, s_L, s_R, blindings8_le32):
+    """The rest of Prover::prove (prover.rs:371-593) over all n = n1 + n2 multipliers -> proof bytes.
+    blindings8_le32: i2, o2, s2, t1, t3, t4, t5, t6."""
+    n = len(a_L)
+    size = lib().bp_r1cs_proof_bytes(ctx.curve, n)
+    out = ctypes.create_string_buffer(size)
+    _check(lib().bp_r1cs_prove_finish(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), bytes(phase1), a_L.h, a_R.h, a_O.h,
+                                      v_blinding.h if v_blinding is not None and len(v_blinding) else None, s_L.h, s_R.h, bytes(blindings8_le32), out, size),
+           "bp_r1cs_prove_finish")
+    return out.raw
+
+
+def r1cs_verify_begin(ctx, transcript, m, proof):
+    """Verifier::verify up to create_randomized_constraints (verifier.rs:276-287, 253); transcript only."""
+    _check(lib().bp_r1cs_verify_begin(transcript.h, ctx.curve, m, bytes(proof), len(proof)), "bp_r1cs_verify_begin")
+
+
+def r1cs_verify_finish(ctx, transcript, plan, G, H, g_le, h_le, V_le, n1, n, proof, r_le32=None):
+    m = len(V_le) // ctx.point_bytes
+    _check(lib().bp_r1cs_verify_finish(ctx.h, transcript.h, plan.h, G.h, H.h, bytes(g_le), bytes(h_le), bytes(V_le) or None, n1, n, m, bytes(proof), len(proof),
+                                       bytes(r_le32) if r_le32 is not None else None), "bp_r1cs_verify_finish")
 
 
 def r1cs_proof_compress(ctx, n, proof):

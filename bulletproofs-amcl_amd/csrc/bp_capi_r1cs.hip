@@ -66,34 +66,50 @@ struct R1cs {
     static constexpr size_t pb = 2 * 4 * C::Fp::NW;
     static constexpr size_t row = sizeof(AffPacked<C>);
 
-    // [G[0..n) | H[0..n) | h] as one resident vector (device-to-device; the generators stay where they are)
-    static int cat_GHh(bp_ctx* ctx, Temps& T, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t n, bp_g1vec** out) {
+    // [G[off..off+n) | H[off..off+n) | h] as one resident vector (device-to-device; the generators stay where they are)
+    static int cat_GHh(bp_ctx* ctx, Temps& T, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t off, size_t n, bp_g1vec** out) {
         bp_g1vec *v = nullptr, *hv = nullptr;
         RC(bp_g1vec_alloc(ctx, 2 * n + 1, &v));
         T.keep(v);
         RC(bp_g1vec_upload(ctx, h_le, 1, BP_FMT_LE, &hv));
         T.keep(hv);
         hipStream_t s = ctx->stream;
-        HIPCHK(hipMemcpyAsync(v->d, G->d, n * row, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync((uint8_t*)v->d + n * row, H->d, n * row, hipMemcpyDeviceToDevice, s));
+        if (n) {
+            HIPCHK(hipMemcpyAsync(v->d, (const uint8_t*)G->d + off * row, n * row, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync((uint8_t*)v->d + n * row, (const uint8_t*)H->d + off * row, n * row, hipMemcpyDeviceToDevice, s));
+        }
         HIPCHK(hipMemcpyAsync((uint8_t*)v->d + 2 * n * row, hv->d, row, hipMemcpyDeviceToDevice, s));
         *out = v;
         return BP_OK;
     }
 
-    // scalars [a | b | c] of  <a, G> + <b, H> + c h  (commit_to_field_element_vectors, prover.rs:346-361); b == nullptr: <a, G> + c h
-    static int commit_scalars(bp_ctx* ctx, Temps& T, size_t n, const bp_frvec* a, const bp_frvec* b, const Fe<F>& c, bp_frvec** out) {
+    // scalars [a[off..off+n) | b[off..off+n) | c] of  <a, G> + <b, H> + c h  (commit_to_field_element_vectors, prover.rs:346-361,
+    // 404-427); b == nullptr: <a, G> + c h
+    static int commit_scalars(bp_ctx* ctx, Temps& T, size_t off, size_t n, const bp_frvec* a, const bp_frvec* b, const Fe<F>& c, bp_frvec** out) {
         bp_frvec *sc = nullptr, *one = nullptr;
         RC(bp_frvec_alloc(ctx, 2 * n + 1, &sc));
         T.keep(sc);
-        RC(bp_frvec_copy(ctx, sc, 0, a, 0, n));
-        if (b) RC(bp_frvec_copy(ctx, sc, n, b, 0, n));
+        if (n) RC(bp_frvec_copy(ctx, sc, 0, a, off, n));
+        if (n && b) RC(bp_frvec_copy(ctx, sc, n, b, off, n));
         std::vector<uint8_t> cle(32);
         fr_out<F>(c, cle.data());
         RC(upload_scalars(ctx, T, cle, &one));
         RC(bp_frvec_copy(ctx, sc, 2 * n, one, 0, 1));
         *out = sc;
         return BP_OK;
+    }
+    // A_I, A_O, S of one phase: the witness slice [off, off + n) against G[off..), H[off..) and h, three MSMs in flight together
+    static int phase_commitments(bp_ctx* ctx, Temps& T, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t off, size_t n, const bp_frvec* aL,
+                                 const bp_frvec* aR, const bp_frvec* aO, const bp_frvec* sL, const bp_frvec* sR, const Fe<F>& i_bl, const Fe<F>& o_bl,
+                                 const Fe<F>& s_bl, uint8_t* P3) {
+        bp_g1vec* GHh = nullptr;
+        RC(cat_GHh(ctx, T, G, H, h_le, off, n, &GHh));
+        bp_frvec* sc3[3] = {nullptr, nullptr, nullptr};
+        RC(commit_scalars(ctx, T, off, n, aL, aR, i_bl, &sc3[0]));
+        RC(commit_scalars(ctx, T, off, n, aO, nullptr, o_bl, &sc3[1]));
+        RC(commit_scalars(ctx, T, off, n, sL, sR, s_bl, &sc3[2]));
+        uint8_t* out3[3] = {P3, P3 + pb, P3 + 2 * pb};
+        return commit_vectors_concurrent(ctx, GHh, sc3, out3, 3);
     }
     // k <= 3 independent commitments over the same [G | H | h]: all in flight at once, on the context and its two siblings (the
     // latency-bound bucket reduce and host tail of one hide behind the accumulate of the others).  Every MSM that was begun is
@@ -126,37 +142,52 @@ struct R1cs {
     // proof layout: A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6 | t_x t_x_blinding e_blinding | L[lg] R[lg] | a b
     static size_t proof_bytes(size_t n) { return 11 * pb + 96 + 2 * lg_of(padded_len(n)) * pb + 64; }
 
+    // Prover::prove up to and including the first-phase commitments (prover.rs:323-366): "m", A_I1, A_O1, S1 on the transcript
+    static int prove_phase1(bp_ctx* ctx, Temps& T, bp_transcript* t, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t m, size_t n1,
+                            const bp_frvec* aL, const bp_frvec* aR, const bp_frvec* aO, const bp_frvec* sL, const bp_frvec* sR, const uint8_t* bl3, uint8_t* P3) {
+        const int cv = ctx->curve;
+        RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // prover.rs:328
+        RC(phase_commitments(ctx, T, G, H, h_le, 0, n1, aL, aR, aO, sL, sR, fr_in<F>(bl3), fr_in<F>(bl3 + 32), fr_in<F>(bl3 + 64), P3));   // :346-361
+        RC(bp_transcript_commit_point(t, cv, "A_I1", P3));
+        RC(bp_transcript_commit_point(t, cv, "A_O1", P3 + pb));
+        RC(bp_transcript_commit_point(t, cv, "S1", P3 + 2 * pb));
+        return BP_OK;
+    }
+
+    // single phase: bl = i1 o1 s1 t1 t3 t4 t5 t6
     static int prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                      const uint8_t* h_le, const bp_frvec* aL, const bp_frvec* aR, const bp_frvec* aO, const bp_frvec* v_blinding, const bp_frvec* sL,
                      const bp_frvec* sR, const uint8_t* bl, uint8_t* proof) {
         Temps T;
+        const size_t n = aL->n, m = v_blinding ? v_blinding->n : 0;
+        memset(proof, 0, proof_bytes(n));
+        RC(prove_phase1(ctx, T, t, G, H, h_le, m, n, aL, aR, aO, sL, sR, bl, proof));
+        RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));  // :304-306
+        uint8_t zero3[96] = {0};
+        return prove_tail(ctx, T, t, plan, G, H, g_le, h_le, n, aL, aR, aO, v_blinding, sL, sR, bl, zero3, bl + 96, proof);
+    }
+
+    // Prover::prove after create_randomized_constraints (prover.rs:371-593).  n1 = first-phase multipliers, the vectors hold all
+    // n = n1 + n2; bl1 = i1 o1 s1, bl2 = i2 o2 s2 (ignored when n2 = 0), tbl = t1 t3 t4 t5 t6.  proof[0..3) already holds A_I1 A_O1 S1.
+    static int prove_tail(bp_ctx* ctx, Temps& T, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                          const uint8_t* h_le, size_t n1, const bp_frvec* aL, const bp_frvec* aR, const bp_frvec* aO, const bp_frvec* v_blinding,
+                          const bp_frvec* sL, const bp_frvec* sR, const uint8_t* bl1, const uint8_t* bl2, const uint8_t* tbl, uint8_t* proof) {
         const int cv = ctx->curve;
-        const size_t n = aL->n, m = v_blinding ? v_blinding->n : 0, pn = padded_len(n), lg = lg_of(pn);
+        const size_t n = aL->n, n2 = n - n1, m = v_blinding ? v_blinding->n : 0, pn = padded_len(n), lg = lg_of(pn);
         uint8_t* P = proof;                                       // the 11 points
         uint8_t* S = proof + 11 * pb;                             // the 3 scalars
         uint8_t* Lp = S + 96;
         uint8_t* Rp = Lp + lg * pb;
         uint8_t* ab = Rp + lg * pb;
-        memset(proof, 0, proof_bytes(n));
-        const Fe<F> i_bl = fr_in<F>(bl), o_bl = fr_in<F>(bl + 32), s_bl = fr_in<F>(bl + 64);
+        const Fe<F> i_bl1 = fr_in<F>(bl1), o_bl1 = fr_in<F>(bl1 + 32), s_bl1 = fr_in<F>(bl1 + 64);
+        Fe<F> i_bl2 = fe_zero<F>(), o_bl2 = fe_zero<F>(), s_bl2 = fe_zero<F>();                                 // :398-402
         Fe<F> tb[7];
-        tb[1] = fr_in<F>(bl + 96); tb[3] = fr_in<F>(bl + 128); tb[4] = fr_in<F>(bl + 160); tb[5] = fr_in<F>(bl + 192); tb[6] = fr_in<F>(bl + 224);
-        RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // prover.rs:328
-        bp_g1vec* GHh = nullptr;
-        RC(cat_GHh(ctx, T, G, H, h_le, n, &GHh));
-        {   // A_I1 (:346-354), A_O1 (:357), S1 (:360-361): independent of each other and of the transcript, computed concurrently
-            bp_frvec* sc3[3] = {nullptr, nullptr, nullptr};
-            RC(commit_scalars(ctx, T, n, aL, aR, i_bl, &sc3[0]));
-            RC(commit_scalars(ctx, T, n, aO, nullptr, o_bl, &sc3[1]));
-            RC(commit_scalars(ctx, T, n, sL, sR, s_bl, &sc3[2]));
-            uint8_t* out3[3] = {P + 0 * pb, P + 1 * pb, P + 2 * pb};
-            RC(commit_vectors_concurrent(ctx, GHh, sc3, out3, 3));
+        tb[1] = fr_in<F>(tbl); tb[3] = fr_in<F>(tbl + 32); tb[4] = fr_in<F>(tbl + 64); tb[5] = fr_in<F>(tbl + 96); tb[6] = fr_in<F>(tbl + 128);
+        if (n2) {                                                                                              // :385-427: A_I2, A_O2, S2 over G[n1..n), H[n1..n)
+            i_bl2 = fr_in<F>(bl2); o_bl2 = fr_in<F>(bl2 + 32); s_bl2 = fr_in<F>(bl2 + 64);
+            RC(phase_commitments(ctx, T, G, H, h_le, n1, n2, aL, aR, aO, sL, sR, i_bl2, o_bl2, s_bl2, P + 3 * pb));
         }
-        RC(bp_transcript_commit_point(t, cv, "A_I1", P + 0 * pb));
-        RC(bp_transcript_commit_point(t, cv, "A_O1", P + 1 * pb));
-        RC(bp_transcript_commit_point(t, cv, "S1", P + 2 * pb));
-        RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));  // :304-306
-        RC(bp_transcript_commit_point(t, cv, "A_I2", P + 3 * pb));                                             // identity, :429-431
+        RC(bp_transcript_commit_point(t, cv, "A_I2", P + 3 * pb));                                             // identity when n2 = 0, :429-434
         RC(bp_transcript_commit_point(t, cv, "A_O2", P + 4 * pb));
         RC(bp_transcript_commit_point(t, cv, "S2", P + 5 * pb));
         const Fe<F> y = challenge(t, cv, "y"), z = challenge(t, cv, "z");
@@ -211,9 +242,10 @@ struct R1cs {
         RC(bp_vecpoly_eval(ctx, rpoly, 3, xle, &r_eval));
         T.keep(r_eval);
         bp_frvec* ippin[4] = {};
-        RC(bp_r1cs_ipp_inputs(ctx, l_eval, r_eval, yle, ule, n, pn, ippin));                                   // :526-563
+        RC(bp_r1cs_ipp_inputs(ctx, l_eval, r_eval, yle, ule, n1, pn, ippin));                                  // :526-563
         for (auto* v : ippin) T.keep(v);
-        const Fe<F> e_bl = fe_mul(x, fe_add(i_bl, fe_mul(x, fe_add(o_bl, fe_mul(x, s_bl)))));                  // :539-543 (second phase = 0)
+        const Fe<F> i_bl = fe_add(i_bl1, fe_mul(u, i_bl2)), o_bl = fe_add(o_bl1, fe_mul(u, o_bl2)), s_bl = fe_add(s_bl1, fe_mul(u, s_bl2));   // :537-539
+        const Fe<F> e_bl = fe_mul(x, fe_add(i_bl, fe_mul(x, fe_add(o_bl, fe_mul(x, s_bl)))));                  // :541
         fr_out<F>(t_x, S); fr_out<F>(t_xb, S + 32); fr_out<F>(e_bl, S + 64);
         RC(bp_transcript_commit_scalar(t, cv, "t_x", S));
         RC(bp_transcript_commit_scalar(t, cv, "t_x_blinding", S + 32));
@@ -235,8 +267,23 @@ struct R1cs {
         return lg_out == lg ? BP_OK : BP_ERR_DEVICE;
     }
 
+    // Verifier::verify up to create_randomized_constraints (verifier.rs:276-284): transcript only
+    static int verify_phase1(bp_transcript* t, int cv, size_t m, const uint8_t* P) {
+        RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // verifier.rs:278
+        RC(bp_transcript_commit_point(t, cv, "A_I1", P + 0 * pb));
+        RC(bp_transcript_commit_point(t, cv, "A_O1", P + 1 * pb));
+        RC(bp_transcript_commit_point(t, cv, "S1", P + 2 * pb));
+        return BP_OK;
+    }
     static int verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                       const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, const uint8_t* r_le32) {
+        RC(verify_phase1(t, ctx->curve, m, proof));
+        RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));
+        return verify_tail(ctx, t, plan, G, H, g_le, h_le, V_le, n, n, m, proof, r_le32);
+    }
+    // Verifier::verify after create_randomized_constraints (verifier.rs:289-457); n1 = first-phase multipliers of the n
+    static int verify_tail(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                           const uint8_t* h_le, const uint8_t* V_le, size_t n1, size_t n, size_t m, const uint8_t* proof, const uint8_t* r_le32) {
         Temps T;
         const int cv = ctx->curve;
         const size_t pn = padded_len(n), lg = lg_of(pn);
@@ -245,11 +292,6 @@ struct R1cs {
         const uint8_t* Lp = S + 96;
         const uint8_t* Rp = Lp + lg * pb;
         const uint8_t* ab = Rp + lg * pb;
-        RC(bp_transcript_append_u64(t, (const uint8_t*)"m", 1, (uint64_t)m));                                  // verifier.rs:278
-        RC(bp_transcript_commit_point(t, cv, "A_I1", P + 0 * pb));
-        RC(bp_transcript_commit_point(t, cv, "A_O1", P + 1 * pb));
-        RC(bp_transcript_commit_point(t, cv, "S1", P + 2 * pb));
-        RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));
         RC(bp_transcript_commit_point(t, cv, "A_I2", P + 3 * pb));
         RC(bp_transcript_commit_point(t, cv, "A_O2", P + 4 * pb));
         RC(bp_transcript_commit_point(t, cv, "S2", P + 5 * pb));
@@ -279,7 +321,7 @@ struct R1cs {
         const Fe<F> delta = fr_in<F>(dle);
         std::vector<uint8_t> usq(lg * 32 + 32), uisq(lg * 32 + 32);
         bp_frvec *g_sc = nullptr, *h_sc = nullptr;
-        RC(bp_r1cs_verifier_scalars(ctx, t, Lp, Rp, lg, pn, n, w[0], w[1], w[2], yile, xle, ule, ab, ab + 32, usq.data(), uisq.data(), &g_sc, &h_sc));   // :354-390
+        RC(bp_r1cs_verifier_scalars(ctx, t, Lp, Rp, lg, pn, n1, w[0], w[1], w[2], yile, xle, ule, ab, ab + 32, usq.data(), uisq.data(), &g_sc, &h_sc));   // :354-390
         T.keep(g_sc);
         T.keep(h_sc);
         const Fe<F> r = fr_in<F>(r_le32);                                                                      // :392
@@ -398,6 +440,99 @@ int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, cons
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
     return R1cs<Bn254>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
+}
+
+// ---- two-phase (randomised) constraint systems: the same functions split where the reference runs the deferred callbacks -------
+namespace {
+struct Phase1Blob {          // what bp_r1cs_prove_finish needs from bp_r1cs_prove_begin; plain bytes in caller memory
+    uint32_t magic, curve;
+    uint64_t n1, m;
+    uint8_t points[3 * 96];  // A_I1 A_O1 S1 (BP_FMT_LE, 2 * fp_bytes each)
+    uint8_t blindings[96];   // i1 o1 s1
+};
+constexpr uint32_t kPhase1Magic = 0x31504842u;   // "BHP1"
+}  // namespace
+
+size_t bp_r1cs_phase1_bytes(void) { return sizeof(Phase1Blob); }
+
+int bp_r1cs_prove_begin(bp_ctx* ctx, bp_transcript* t, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t m, const bp_frvec* a_L1,
+                        const bp_frvec* a_R1, const bp_frvec* a_O1, const bp_frvec* s_L1, const bp_frvec* s_R1, const uint8_t* blindings3_le32,
+                        uint8_t* phase1_out, size_t phase1_cap) {
+    if (!ctx || !t || !G || !H || !h_le || !blindings3_le32 || !phase1_out) return BP_ERR_ARG;
+    if (phase1_cap < sizeof(Phase1Blob)) return BP_ERR_LENGTH;
+    const size_t n1 = a_L1 ? a_L1->n : 0;
+    if (n1 && (!a_R1 || !a_O1 || !s_L1 || !s_R1)) return BP_ERR_ARG;
+    if (n1 && (a_R1->n != n1 || a_O1->n != n1 || s_L1->n != n1 || s_R1->n != n1)) return BP_ERR_LENGTH;
+    if (G->n < n1 || H->n < n1) return BP_ERR_LENGTH;                      // prover.rs:333
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    Phase1Blob b;
+    memset(&b, 0, sizeof b);
+    b.magic = kPhase1Magic; b.curve = (uint32_t)ctx->curve; b.n1 = n1; b.m = m;
+    memcpy(b.blindings, blindings3_le32, 96);
+    Temps T;
+    uint8_t P3[3 * 96] = {0};
+    if (ctx->curve == BP_CURVE_BLS12_381) rc = R1cs<Bls381>::prove_phase1(ctx, T, t, G, H, h_le, m, n1, a_L1, a_R1, a_O1, s_L1, s_R1, blindings3_le32, P3);
+    else rc = R1cs<Bn254>::prove_phase1(ctx, T, t, G, H, h_le, m, n1, a_L1, a_R1, a_O1, s_L1, s_R1, blindings3_le32, P3);
+    if (rc) return rc;
+    memcpy(b.points, P3, sizeof P3);
+    RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-2phase", 11));      // prover.rs:308
+    memcpy(phase1_out, &b, sizeof b);
+    return BP_OK;
+}
+
+int bp_r1cs_prove_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                         const uint8_t* h_le, const uint8_t* phase1, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O,
+                         const bp_frvec* v_blinding, const bp_frvec* s_L, const bp_frvec* s_R, const uint8_t* blindings8_le32, uint8_t* proof_out,
+                         size_t proof_cap) {
+    if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || !phase1 || !a_L || !a_R || !a_O || !s_L || !s_R || !blindings8_le32 || !proof_out) return BP_ERR_ARG;
+    Phase1Blob b;
+    memcpy(&b, phase1, sizeof b);
+    if (b.magic != kPhase1Magic || b.curve != (uint32_t)ctx->curve) return BP_ERR_ARG;
+    const size_t n = a_L->n, m = v_blinding ? v_blinding->n : 0;
+    if (n == 0 || b.n1 > n || b.m != m) return BP_ERR_ARG;
+    if (a_R->n != n || a_O->n != n || s_L->n != n || s_R->n != n) return BP_ERR_LENGTH;
+    size_t pn = 1;
+    while (pn < n) pn <<= 1;
+    if (G->n < pn || H->n < pn) return BP_ERR_LENGTH;                      // prover.rs:382
+    if (proof_cap < bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_LENGTH;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    memset(proof_out, 0, bp_r1cs_proof_bytes(ctx->curve, n));
+    Temps T;
+    if (ctx->curve == BP_CURVE_BLS12_381) {
+        memcpy(proof_out, b.points, 3 * R1cs<Bls381>::pb);
+        return R1cs<Bls381>::prove_tail(ctx, T, t, plan, G, H, g_le, h_le, (size_t)b.n1, a_L, a_R, a_O, v_blinding, s_L, s_R, b.blindings, blindings8_le32,
+                                        blindings8_le32 + 96, proof_out);
+    }
+    memcpy(proof_out, b.points, 3 * R1cs<Bn254>::pb);
+    return R1cs<Bn254>::prove_tail(ctx, T, t, plan, G, H, g_le, h_le, (size_t)b.n1, a_L, a_R, a_O, v_blinding, s_L, s_R, b.blindings, blindings8_le32,
+                                   blindings8_le32 + 96, proof_out);
+}
+
+int bp_r1cs_verify_begin(bp_transcript* t, int curve_id, size_t m, const uint8_t* proof, size_t proof_len) {
+    if (!t || !proof || !curve_ok(curve_id)) return BP_ERR_ARG;
+    const size_t pb = curve_id == BP_CURVE_BLS12_381 ? R1cs<Bls381>::pb : R1cs<Bn254>::pb;
+    if (proof_len < 3 * pb) return BP_ERR_VERIFY;
+    RC(curve_id == BP_CURVE_BLS12_381 ? R1cs<Bls381>::verify_phase1(t, curve_id, m, proof) : R1cs<Bn254>::verify_phase1(t, curve_id, m, proof));
+    return bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-2phase", 11);  // verifier.rs:253
+}
+
+int bp_r1cs_verify_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                          const uint8_t* h_le, const uint8_t* V_le, size_t n1, size_t n, size_t m, const uint8_t* proof, size_t proof_len,
+                          const uint8_t* r_le32) {
+    if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || (m && !V_le) || !proof || n == 0 || n1 > n) return BP_ERR_ARG;
+    if (proof_len != bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_VERIFY;
+    size_t pn = 1;
+    while (pn < n) pn <<= 1;
+    if (G->n < pn || H->n < pn) return BP_ERR_LENGTH;                      // verifier.rs:296-298
+    uint8_t rbuf[32];
+    if (!r_le32) {
+        int rcr = bp_fr_random(ctx->curve, rbuf, 1);
+        if (rcr) return rcr;
+        r_le32 = rbuf;
+    } else if (!bp_fr_is_canonical_nonzero(ctx->curve, r_le32)) return BP_ERR_ARG;
+    int rc = bp_internal_set_device(ctx); if (rc) return rc;
+    if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::verify_tail(ctx, t, plan, G, H, g_le, h_le, V_le, n1, n, m, proof, r_le32);
+    return R1cs<Bn254>::verify_tail(ctx, t, plan, G, H, g_le, h_le, V_le, n1, n, m, proof, r_le32);
 }
 
 }  // extern "C"

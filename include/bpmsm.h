@@ -345,6 +345,32 @@ int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const
                   const bp_frvec* s_R, const uint8_t* blindings_le32, uint8_t* proof_out, size_t proof_cap);
 int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                    const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, size_t proof_len, const uint8_t* r_le32);
+/* Two-phase (randomised) constraint systems: Prover::prove / Verifier::verify split at create_randomized_constraints
+ * (src/r1cs/prover.rs:298-319, verifier.rs:245-263), where the reference runs the callbacks registered with
+ * specify_randomized_constraints (constraint_system.rs:77-99).  The caller plays that role between the two calls:
+ *   bp_r1cs_prove_begin    appends "m", commits A_I1 / A_O1 / S1 of the n1 first-phase multipliers (vectors may be NULL when
+ *                          n1 = 0) and the "r1cs-2phase" domain separator; blindings3 = i_blinding1, o_blinding1, s_blinding1.
+ *                          phase1_out (bp_r1cs_phase1_bytes() bytes, caller memory) carries what _finish needs.
+ *   ... the callbacks: RandomizedConstraintSystem::challenge_scalar(label) = bp_transcript_challenge_scalar(t, curve, label, ..);
+ *       allocate second-phase multipliers and constraints; build the plan of the COMPLETE system (bp_r1cs_plan_create) ...
+ *   bp_r1cs_prove_finish   a_L, a_R, a_O, s_L, s_R now hold all n = n1 + n2 entries (the first n1 as given to _begin); commits
+ *                          A_I2 / A_O2 / S2 over G[n1..n), H[n1..n) (prover.rs:385-434) and finishes the proof.
+ *                          blindings8 = i_blinding2, o_blinding2, s_blinding2, t_1, t_3, t_4, t_5, t_6 blindings.
+ *   bp_r1cs_verify_begin   transcript only: "m", A_I1, A_O1, S1, the domain separator (verifier.rs:276-287, 253).
+ *   bp_r1cs_verify_finish  the rest of Verifier::verify for n1 first-phase multipliers out of n; r_le32 as in bp_r1cs_verify.
+ * The single-phase bp_r1cs_prove / bp_r1cs_verify are these with n2 = 0 and the "r1cs-1phase" separator. */
+size_t bp_r1cs_phase1_bytes(void);
+int bp_r1cs_prove_begin(bp_ctx* ctx, bp_transcript* t, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t m, const bp_frvec* a_L1,
+                        const bp_frvec* a_R1, const bp_frvec* a_O1, const bp_frvec* s_L1, const bp_frvec* s_R1, const uint8_t* blindings3_le32,
+                        uint8_t* phase1_out, size_t phase1_cap);
+int bp_r1cs_prove_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                         const uint8_t* h_le, const uint8_t* phase1, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O,
+                         const bp_frvec* v_blinding, const bp_frvec* s_L, const bp_frvec* s_R, const uint8_t* blindings8_le32, uint8_t* proof_out,
+                         size_t proof_cap);
+int bp_r1cs_verify_begin(bp_transcript* t, int curve_id, size_t m, const uint8_t* proof, size_t proof_len);
+int bp_r1cs_verify_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
+                          const uint8_t* h_le, const uint8_t* V_le, size_t n1, size_t n, size_t m, const uint8_t* proof, size_t proof_len,
+                          const uint8_t* r_le32);
 /* Prover, src/r1cs/prover.rs:465-486.  in = {a_L, a_R, a_O, s_L, s_R, wL, wR, wO} (equal lengths n; wL.. are the
  * flattened constraints, computed on the host); out = {l1, l2, l3, r0, r1, r3}: the non-zero coefficient vectors of
  * l(X) = l1 X + l2 X^2 + l3 X^3 and r(X) = r0 + r1 X + r3 X^3 (feed bp_vecpoly3_special_inner_product / bp_vecpoly_eval). */

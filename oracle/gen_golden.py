@@ -363,6 +363,100 @@ def gen_r1cs():
     return out
 
 
+def gen_r1cs2():
+    """Two-phase (randomised) R1CS proofs: pyref.r1cs_prove with deferred constraints (src/r1cs/prover.rs:298-319,383-431,
+    verifier.rs:245-263).  The circuit is pyref.shuffle_gadget (a challenge z drawn after A_I1 / A_O1 / S1, then
+    prod (x_i - z) = prod (y_i - z)); the reference ships the mechanism but no gadget using it.
+      shuffle_2               no first-phase multipliers at all (n1 = 0: A_I1 = i_blinding1 h), two in the second phase
+      product_then_shuffle_3  one first-phase gate (x0 x1 = p), four second-phase gates, 5 gates padded to 8
+    Each case holds what the split C ABI (bp_r1cs_prove_begin / _finish, bp_r1cs_verify_begin / _finish) needs: the first-phase part,
+    the challenge the circuit draws (label and expected value) and the complete system as flat terms."""
+    out = {}
+    for c in (R.BLS12_381, R.BN254):
+        rng = R.SplitMix64(SEED + 950 + c.curve_id)
+        g, hh = R.g1_from_msg_hash(c, b"g"), R.g1_from_msg_hash(c, b"h")
+        cases = []
+
+        def build_shuffle2(cs, comms):
+            xs_val, ys_val = (5, 9), (9, 5)
+            if comms is None:
+                cm = [cs.commit(v, rng.scalar(c)) for v in xs_val + ys_val]
+                V, vars_ = [a for a, _ in cm], [b for _, b in cm]
+            else:
+                V, vars_ = None, [cs.commit(P) for P in comms]
+            R.shuffle_gadget(cs, vars_[:2], vars_[2:])
+            return V
+
+        def build_product_shuffle3(cs, comms):
+            xs_val, ys_val, pv = (3, 11, 7), (7, 3, 11), 33
+            if comms is None:
+                cm = [cs.commit(v, rng.scalar(c)) for v in xs_val + ys_val + (pv,)]
+                V, vars_ = [a for a, _ in cm], [b for _, b in cm]
+            else:
+                V, vars_ = None, [cs.commit(P) for P in comms]
+            _, _, o = cs.multiply([(vars_[0], 1)], [(vars_[1], 1)])                  # first phase: x0 x1 = p
+            cs.constrain(R.lc_sub(c, [(o, 1)], [(vars_[6], 1)]))
+            R.shuffle_gadget(cs, vars_[:3], vars_[3:6])
+            return V
+
+        for name, label, ngens, build in (("shuffle_2", b"Shuffle2", 2, build_shuffle2), ("product_then_shuffle_3", b"ProductShuffle3", 8, build_product_shuffle3)):
+            G, H = R.get_generators(c, "G", ngens), R.get_generators(c, "H", ngens)
+            tr = R.Transcript(label)
+            prover = R.R1CSProver(c, g, hh, tr)
+            V = build(prover, None)
+            n1, m, q1 = len(prover.aL), len(prover.v), len(prover.constraints)
+            seen = {}
+            real_challenge = tr.challenge_scalar
+            def spy(curve, lbl, _real=real_challenge, _seen=seen):
+                v = _real(curve, lbl)
+                if lbl == b"shuffle challenge":
+                    _seen["z"] = v
+                return v
+            tr.challenge_scalar = spy
+            # the second-phase sizes are known from the circuit shape: k - 1 multipliers per side
+            k = 2 if name == "shuffle_2" else 3
+            n2 = 2 * (k - 1)
+            rand = {"i_blinding1": rng.scalar(c), "o_blinding1": rng.scalar(c), "s_blinding1": rng.scalar(c),
+                    "s_L1": [rng.scalar(c) for _ in range(n1)], "s_R1": [rng.scalar(c) for _ in range(n1)],
+                    "i_blinding2": rng.scalar(c), "o_blinding2": rng.scalar(c), "s_blinding2": rng.scalar(c),
+                    "s_L2": [rng.scalar(c) for _ in range(n2)], "s_R2": [rng.scalar(c) for _ in range(n2)]}
+            for kk in (1, 3, 4, 5, 6):
+                rand["t_%d_blinding" % kk] = rng.scalar(c)
+            proof = R.r1cs_prove(prover, G, H, rand)
+            n = len(prover.aL)
+            assert n - n1 == n2 and "z" in seen
+            assert all(prover.eval(lc) == 0 for lc in prover.constraints), "fixture circuit is not satisfied"
+            rv = rng.scalar(c)
+            ver = R.R1CSVerifier(c, R.Transcript(label))
+            build(ver, list(V))
+            sc, pts = R.r1cs_verifier_msm(ver, proof, g, hh, G, H, rv)
+            assert ver.constraints == prover.constraints and ver.num_vars == n
+            assert c.msm(sc, pts) is None, "fixture proof does not verify"
+            # a y that is not a permutation of x must not verify: swap in a proof made for other commitments
+            bad = dict(proof, t_x=(proof["t_x"] + 1) % c.r)
+            ver2 = R.R1CSVerifier(c, R.Transcript(label))
+            build(ver2, list(V))
+            assert not R.r1cs_verify(ver2, bad, g, hh, G, H, rv)
+            terms = R.constraints_to_terms(prover.constraints)
+            cases.append({
+                "name": name, "label": h(label), "n1": n1, "n2": n2, "m": m, "n_constraints_phase1": q1, "n_constraints": len(prover.constraints),
+                "n_generators": ngens, "challenge_label": h(b"shuffle challenge"), "challenge": fr_le(c, seen["z"]),
+                "terms": [[q, kd, i, fr_le(c, cf)] for q, kd, i, cf in terms],
+                "g": pt_le(c, g), "h": pt_le(c, hh), "G": [pt_le(c, P) for P in G], "H": [pt_le(c, P) for P in H],
+                "V": [pt_le(c, P) for P in V],
+                "a_L": [fr_le(c, x) for x in prover.aL], "a_R": [fr_le(c, x) for x in prover.aR], "a_O": [fr_le(c, x) for x in prover.aO],
+                "v": [fr_le(c, x) for x in prover.v], "v_blinding": [fr_le(c, x) for x in prover.v_blinding],
+                "s_L": [fr_le(c, x) for x in rand["s_L1"] + rand["s_L2"]], "s_R": [fr_le(c, x) for x in rand["s_R1"] + rand["s_R2"]],
+                "blindings": [fr_le(c, rand[kk]) for kk in ("i_blinding1", "o_blinding1", "s_blinding1", "i_blinding2", "o_blinding2", "s_blinding2",
+                                                            "t_1_blinding", "t_3_blinding", "t_4_blinding", "t_5_blinding", "t_6_blinding")],
+                "proof": h(R.r1cs_proof_to_le(c, proof)),
+                "verifier_r": fr_le(c, rv), "verifier_msm_scalars": [fr_le(c, x) for x in sc],
+            })
+            print("  r1cs2", c.name, name, "gates", n1, "+", n2, file=sys.stderr)
+        out[c.name] = cases
+    return out
+
+
 def gen_compressed():
     """bp_g1vec_compress / _decompress (this build's tag || X form, pyref.g1_compress): multiples of the generator with both y
     parities, the identity, hashed points; and encodings that must be refused."""
@@ -397,7 +491,7 @@ def gen_compressed():
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("curves", gen_curves), ("field", gen_field), ("g1", gen_g1), ("merlin", gen_merlin),
-                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1), ("r1cs", gen_r1cs), ("compressed", gen_compressed)):
+                     ("msm", gen_msm), ("ipp", gen_ipp), ("hash_to_g1", gen_hash_to_g1), ("r1cs", gen_r1cs), ("r1cs2", gen_r1cs2), ("compressed", gen_compressed)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue                                                   # python3 oracle/gen_golden.py r1cs  -> only that file
         print("generating", name, file=sys.stderr)

@@ -658,6 +658,27 @@ def verify_bounded_num(verifier, lower, upper, bits, commitments):
     bound_check_gadget(verifier, vv, va, vb, upper, lower, bits)
 
 
+def shuffle_gadget(cs, xs, ys):
+    """A k-element shuffle as a SECOND-PHASE gadget -- the canonical use of specify_randomized_constraints
+    (src/r1cs/constraint_system.rs:77-99; the reference ships the mechanism, prover.rs:298-319 / verifier.rs:245-263, but no gadget
+    that uses it): with a challenge z drawn after the first-phase commitments,  prod (x_i - z) = prod (y_i - z).
+    xs, ys: variables.  Works on both sides: the prover's multiply() evaluates the operands, the verifier's only allocates."""
+    assert len(xs) == len(ys) and len(xs) >= 2
+    c = cs.curve
+
+    def second_phase(rcs):
+        z = rcs.challenge_scalar(b"shuffle challenge")
+        def product(vs):
+            _, _, o = rcs.multiply(lc_sub(c, [(vs[-1], 1)], lc_scalar(c, z)), lc_sub(c, [(vs[-2], 1)], lc_scalar(c, z)))
+            for v in reversed(vs[:-2]):
+                _, _, o = rcs.multiply([(o, 1)], lc_sub(c, [(v, 1)], lc_scalar(c, z)))
+            return o
+        ox, oy = product(list(xs)), product(list(ys))
+        rcs.constrain(lc_sub(c, [(ox, 1)], [(oy, 1)]))
+
+    cs.specify_randomized_constraints(second_phase)
+
+
 def _flatten(curve, constraints, z, n, m):
     """flattened_constraints: prover.rs:142-184 / verifier.rs:149-193 (wc only matters to the verifier)."""
     r = curve.r

@@ -5,7 +5,10 @@ whole proofs made outside the product --
   * BASELINE config 3 at full size: 1024 chained 32-bit bound checks (65 536 gates, 136 192 constraints, m = 3 072) built by the
     oracle's restatement of the gadgets (src/r1cs/gadgets/bound_check.rs:13-39, helper_constraints/positive_no.rs:8-40), proven
     by the library and by the C oracle (oracle/orc_r1cs_tmpl.h): same bytes, and each verifier accepts the other's proof;
-  * an inner-product argument at n = 2^16 against the C oracle's create_ipp / verify_ipp.
+  * an inner-product argument at n = 2^16 against the C oracle's create_ipp / verify_ipp;
+  * tests/golden/r1cs2.json: TWO-PHASE (randomised) systems -- a shuffle gadget whose constraints depend on a challenge drawn after the
+    first-phase commitments (prover.rs:298-319,383-431; verifier.rs:245-263) -- through bp_r1cs_prove_begin / _finish and
+    bp_r1cs_verify_begin / _finish, byte for byte against oracle/pyref.py.
 PARITY UNPINNED w.r.t. the reference itself: the oracle is a restatement."""
 import os
 import sys
@@ -96,6 +99,58 @@ def test_r1cs_golden_fixture(bp, golden, name):
             with pytest.raises(bp.VerificationError):
                 bp.r1cs_verify(ctx, start_transcript(bp, ctx, a["label"], a["V"]), plan, Gv, Hv, a["g"], a["h"], O.generator(ctx.curve) + Vb[pb:], n,
                                a["proof"], a["r"])
+        plan.free()
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_r1cs_two_phase_fixture(bp, golden, name):
+    """Deferred (randomised) constraints through the split API: begin commits the first phase, the test plays the callback (draws the
+    circuit's challenge from the SAME transcript and checks it against the oracle's), finish commits the second phase over
+    G[n1..n), H[n1..n) and completes the proof; both verifier halves likewise.  n1 = 0 (no first-phase multiplier) is one of the cases."""
+    ctx = bp.Context(bp.CURVE_IDS[name], 0)
+    pb = ctx.point_bytes
+    for c in golden("r1cs2")[name]:
+        a = r1cs_case_inputs(c)
+        n1, n2, m, ng = c["n1"], c["n2"], c["m"], c["n_generators"]
+        n = n1 + n2
+        Gv, Hv = bp.G1Vector.from_bytes(ctx, a["G"], ng), bp.G1Vector.from_bytes(ctx, a["H"], ng)
+        fe = lambda b, k: bp.FieldElementVector.from_bytes(ctx, b, k) if k else None
+        blind = a["blind"]                                   # i1 o1 s1 | i2 o2 s2 | t1 t3 t4 t5 t6
+        t = start_transcript(bp, ctx, a["label"], a["V"])
+        phase1 = bp.r1cs_prove_begin(ctx, t, Gv, Hv, a["h"], m, fe(a["aL"][:32 * n1], n1), fe(a["aR"][:32 * n1], n1), fe(a["aO"][:32 * n1], n1),
+                                     fe(a["sL"][:32 * n1], n1), fe(a["sR"][:32 * n1], n1), blind[:96])
+        z = t.challenge_scalar(ctx.curve, bytes.fromhex(c["challenge_label"]))          # the callback's challenge_scalar
+        assert z == bytes.fromhex(c["challenge"]), (name, c["name"], "the circuit's challenge differs from the oracle's")
+        plan = bp.R1CSPlan(ctx, a["terms"], c["n_constraints"], n, m)                    # the complete system, second-phase terms included
+        proof = bp.r1cs_prove_finish(ctx, t, plan, Gv, Hv, a["g"], a["h"], phase1, fe(a["aL"], n), fe(a["aR"], n), fe(a["aO"], n),
+                                     fe(a["vb"], m), fe(a["sL"], n), fe(a["sR"], n), blind[96:])
+        assert proof == a["proof"], (name, c["name"])
+        assert proof[3 * pb:6 * pb] != bytes(3 * pb)                                     # A_I2, A_O2, S2 are real commitments here
+        Vb = b"".join(a["V"])
+
+        def verify(pr, V=Vb, n1_=n1):
+            tv = start_transcript(bp, ctx, a["label"], [V[k * pb:(k + 1) * pb] for k in range(m)])
+            bp.r1cs_verify_begin(ctx, tv, m, pr)
+            assert tv.challenge_scalar(ctx.curve, bytes.fromhex(c["challenge_label"])) is not None
+            bp.r1cs_verify_finish(ctx, tv, plan, Gv, Hv, a["g"], a["h"], V, n1_, n, pr, a["r"])
+
+        verify(a["proof"])
+        for pos in (0, 3 * pb, 4 * pb + 1, 11 * pb, len(a["proof"]) - 1):                # A_I1, A_I2, A_O2, t_x, b
+            bad = bytearray(a["proof"])
+            bad[pos] ^= 1
+            with pytest.raises(bp.VerificationError):
+                verify(bytes(bad))
+        with pytest.raises(bp.VerificationError):                                        # the phase boundary is part of the statement (G_factors)
+            verify(a["proof"], n1_=n1 + 1)
+        with pytest.raises(bp.VerificationError):                                        # another commitment: y is no longer a permutation of x
+            verify(a["proof"], V=O.generator(ctx.curve) + Vb[pb:])
+        # a single-phase call on the same data must not produce or accept this proof (domain separator, G_factors)
+        with pytest.raises(bp.VerificationError):
+            bp.r1cs_verify(ctx, start_transcript(bp, ctx, a["label"], a["V"]), plan, Gv, Hv, a["g"], a["h"], Vb, n, a["proof"], a["r"])
+        with pytest.raises(bp.ArgError):
+            bp.r1cs_prove_finish(ctx, t, plan, Gv, Hv, a["g"], a["h"], bytes(len(phase1)), fe(a["aL"], n), fe(a["aR"], n), fe(a["aO"], n),
+                                 fe(a["vb"], m), fe(a["sL"], n), fe(a["sR"], n), blind[96:])
         plan.free()
     ctx.close()
 
