@@ -351,7 +351,7 @@ def batch_verify():
 def msm_sweep():
     """north_star: MSM throughput at n = 2^16 .. 2^22 on one GPU (BLS12-381), every result checked by linearity:
     MSM(s, k.G) == (<s, k> mod r).G with the inner product from the oracle."""
-    out = {"config": "msm_sweep: BLS12-381 G1 MSM, uniform scalars, points k_i*G, inputs resident, best of 5"}
+    out = {"config": "msm_sweep: BLS12-381 G1 MSM, uniform scalars, points k_i*G, inputs resident, best of 10 (the first few calls of a size run ~5 % slower: clocks)"}
     ctx = bp.Context(bp.BLS12_381, 0)
     info = bp.curve_info(ctx.curve)
     for lg in (16, 17, 18, 19, 20, 21, 22):
@@ -361,7 +361,7 @@ def msm_sweep():
         Pv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, kb, n))
         sv = bp.FieldElementVector.from_bytes(ctx, sb, n)
         Pv.multi_scalar_mul_var_time(sv)
-        t, got = best_of(lambda: Pv.multi_scalar_mul_var_time(sv), reps=5)
+        t, got = best_of(lambda: Pv.multi_scalar_mul_var_time(sv), reps=10)
         want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, kb, sb, n), O.generator(ctx.curve))
         out["n=2^%d" % lg] = {"ms": t * 1e3, "scalar_muls_per_s": n / t, "ok": bool(got == want),
                               "algorithmic_GBs": n * (2 * info.fp_bytes + 32) / t / 1e9}
