@@ -332,6 +332,39 @@ inline void verify(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Ve
           "bp_r1cs_verify");
 }
 
+// Randomised (two-phase) systems: Prover::prove / Verifier::verify split where the reference runs the callbacks of
+// specify_randomized_constraints (prover.rs:298-319, verifier.rs:245-263).  Between begin and finish the caller draws the
+// callbacks' challenges from the same transcript (Transcript::challenge_scalar) and builds the plan of the complete system.
+inline Bytes prove_begin(Context& ctx, Transcript& t, const G1Vector& G, const G1Vector& H, const Bytes& h, size_t m, const FieldElementVector* a_L1,
+                         const FieldElementVector* a_R1, const FieldElementVector* a_O1, const FieldElementVector* s_L1, const FieldElementVector* s_R1,
+                         const Bytes& blindings3) {
+    Bytes phase1(bp_r1cs_phase1_bytes());
+    auto hd = [](const FieldElementVector* v) { return v ? v->handle() : nullptr; };
+    check(bp_r1cs_prove_begin(ctx.handle(), t.handle(), G.handle(), H.handle(), h.data(), m, hd(a_L1), hd(a_R1), hd(a_O1), hd(s_L1), hd(s_R1), blindings3.data(),
+                              phase1.data(), phase1.size()),
+          "bp_r1cs_prove_begin");
+    return phase1;
+}
+// blindings8 = i2, o2, s2, t1, t3, t4, t5, t6; the vectors hold all n1 + n2 multipliers
+inline Bytes prove_finish(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Vector& G, const G1Vector& H, const Bytes& g, const Bytes& h,
+                          const Bytes& phase1, const FieldElementVector& a_L, const FieldElementVector& a_R, const FieldElementVector& a_O,
+                          const FieldElementVector* v_blinding, const FieldElementVector& s_L, const FieldElementVector& s_R, const Bytes& blindings8) {
+    Bytes proof(bp_r1cs_proof_bytes(ctx.curve(), a_L.len()));
+    check(bp_r1cs_prove_finish(ctx.handle(), t.handle(), plan.handle(), G.handle(), H.handle(), g.data(), h.data(), phase1.data(), a_L.handle(), a_R.handle(),
+                               a_O.handle(), v_blinding ? v_blinding->handle() : nullptr, s_L.handle(), s_R.handle(), blindings8.data(), proof.data(), proof.size()),
+          "bp_r1cs_prove_finish");
+    return proof;
+}
+inline void verify_begin(Context& ctx, Transcript& t, size_t m, const Bytes& proof) {
+    check(bp_r1cs_verify_begin(t.handle(), ctx.curve(), m, proof.data(), proof.size()), "bp_r1cs_verify_begin");
+}
+inline void verify_finish(Context& ctx, Transcript& t, const R1CSPlan& plan, const G1Vector& G, const G1Vector& H, const Bytes& g, const Bytes& h, const Bytes& V,
+                          size_t n1, const Bytes& proof, const Bytes& r_weight_le32 = Bytes()) {
+    check(bp_r1cs_verify_finish(ctx.handle(), t.handle(), plan.handle(), G.handle(), H.handle(), g.data(), h.data(), V.empty() ? nullptr : V.data(), n1, plan.n(),
+                                V.size() / ctx.point_bytes(), proof.data(), proof.size(), r_weight_le32.empty() ? nullptr : r_weight_le32.data()),
+          "bp_r1cs_verify_finish");
+}
+
 // serde of R1CSProof (src/r1cs/proof.rs:24) in this build's compressed point form; a bad encoding -> VerificationError
 inline Bytes compress_proof(Context& ctx, size_t n_gates, const Bytes& proof) {
     Bytes out(bp_r1cs_proof_compressed_bytes(ctx.curve(), n_gates));
