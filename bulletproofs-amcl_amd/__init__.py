@@ -144,6 +144,7 @@ SYMBOLS = {
     "bp_transcript_append_u64": (_I, [_P, _U8P, _SZ, ctypes.c_uint64]),
     "bp_transcript_challenge_bytes": (_I, [_P, _U8P, _SZ, _U8P, _SZ]),
     "bp_transcript_commit_point": (_I, [_P, _I, _U8P, _U8P]),
+    "bp_transcript_commit_points": (_I, [_P, _I, _U8P, _U8P, _SZ]),
     "bp_transcript_commit_scalar": (_I, [_P, _I, _U8P, _U8P]),
     "bp_transcript_challenge_scalar": (_I, [_P, _I, _U8P, _U8P]),
     "bp_ipp_state_create": (_I, [_P, _P, _P, _U8P, _P, _P, _P, _P, _PP]),
@@ -587,6 +588,10 @@ class Transcript:
 
     def commit_point(self, curve, label, point_le):
         _check(lib().bp_transcript_commit_point(self.h, curve, label, bytes(point_le)), "commit_point")
+
+    def commit_points(self, curve, label, points_le, n):
+        """n commit_point calls with the same label in one library call (the V commitments of a statement)."""
+        _check(lib().bp_transcript_commit_points(self.h, curve, label, bytes(points_le), n), "commit_points")
 
     def commit_scalar(self, curve, label, scalar_le32):
         _check(lib().bp_transcript_commit_scalar(self.h, curve, label, bytes(scalar_le32)), "commit_scalar")

@@ -528,6 +528,14 @@ int bp_transcript_commit_point(bp_transcript* t, int curve_id, const char* label
     if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_point(t->t, label, point_le); else Ipp<Bn254>::commit_point(t->t, label, point_le);
     return BP_OK;
 }
+int bp_transcript_commit_points(bp_transcript* t, int curve_id, const char* label, const uint8_t* points_le, size_t n) {
+    if (!t || !curve_ok(curve_id) || !label || (!points_le && n)) return BP_ERR_ARG;
+    const size_t pb = curve_id == BP_CURVE_BLS12_381 ? 2 * 4 * Bls381::Fp::NW : 2 * 4 * Bn254::Fp::NW;
+    for (size_t i = 0; i < n; i++) {
+        if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_point(t->t, label, points_le + i * pb); else Ipp<Bn254>::commit_point(t->t, label, points_le + i * pb);
+    }
+    return BP_OK;
+}
 int bp_transcript_commit_scalar(bp_transcript* t, int curve_id, const char* label, const uint8_t* scalar_le32) {
     if (!t || !curve_ok(curve_id) || !label || !scalar_le32) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_scalar(t->t, label, scalar_le32); else Ipp<Bn254>::commit_scalar(t->t, label, scalar_le32);

@@ -64,8 +64,7 @@ class Generators:
 def start_transcript(ctx, label, V):
     t = bp.Transcript(label)
     t.append_message(b"dom-sep", b"r1cs v1")                      # r1cs_domain_sep, src/transcript.rs:35-37
-    for Vj in V:
-        t.commit_point(ctx.curve, b"V", Vj)                       # Prover::commit, prover.rs:118-127
+    t.commit_points(ctx.curve, b"V", b"".join(V), len(V))         # Prover::commit per value, prover.rs:118-127 (one call for all of them)
     return t
 
 

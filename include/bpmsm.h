@@ -243,6 +243,8 @@ int bp_transcript_append_u64(bp_transcript* t, const uint8_t* label, size_t labe
 int bp_transcript_challenge_bytes(bp_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
 /* commit_point: append_message(label, G1::to_bytes())          (src/transcript.rs:51-53); point given as BP_FMT_LE */
 int bp_transcript_commit_point(bp_transcript* t, int curve_id, const char* label, const uint8_t* point_le);
+/* n commit_point calls with the same label (the "V" commitments of Prover::commit / Verifier::commit, prover.rs:118-127): one call. */
+int bp_transcript_commit_points(bp_transcript* t, int curve_id, const char* label, const uint8_t* points_le, size_t n);
 /* commit_scalar: append_message(label, FieldElement::to_bytes()) (src/transcript.rs:47-49) */
 int bp_transcript_commit_scalar(bp_transcript* t, int curve_id, const char* label, const uint8_t* scalar_le32);
 /* challenge_scalar: MODBYTES challenge bytes -> FieldElement::from (src/transcript.rs:55-60) */
