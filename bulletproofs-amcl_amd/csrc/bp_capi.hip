@@ -234,14 +234,12 @@ struct Impl {
         const size_t nhist = (size_t)rows * ntiles;
         const size_t hist_blocks = (nhist + kScanPerBlock - 1) / kScanPerBlock;
         if ((rc = ctx->tile_hist.reserve(nhist * 4))) return rc;
-        if ((rc = ctx->tmp_code.reserve((size_t)W * n * 2))) return rc;
-        if ((rc = ctx->tmp_idx.reserve((size_t)W * n * 4))) return rc;
+        if ((rc = ctx->tmp_idx.reserve((size_t)W * n * 8))) return rc;            // (point index, digit code) records of the coarse pass
         if ((rc = ctx->block_sums.reserve((hist_blocks + 16 + tot_bsum) * 4))) return rc;
         uint32_t* hsum = (uint32_t*)ctx->block_sums.p;                 // scan of the tile histogram; hsum[hist_blocks] = grand total
         uint32_t* gsum = hsum + hist_blocks + 16;                      // per-group task scans
         uint32_t* tile_hist = (uint32_t*)ctx->tile_hist.p;
-        uint16_t* tmp_code = (uint16_t*)ctx->tmp_code.p;
-        uint32_t* tmp_idx = (uint32_t*)ctx->tmp_idx.p;
+        uint2* tmp_rec = (uint2*)ctx->tmp_idx.p;
 
         const bool tm = ctx->timing;
         if ((rc = ensure_events(ctx))) return rc;
@@ -283,9 +281,9 @@ struct Impl {
             uint32_t* heavy = (uint32_t*)ctx->heavy.p + q.heavy_base;
             uint2* chunks = (uint2*)ctx->heavy_chunks.p + q.chunk_base;
             uint32_t* bsum = gsum + q.bsum_base;
-            hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, Wg), dim3(kBlock), 0, sk, code, n, tab, ntiles, tile_hist, tmp_code, tmp_idx, q.w0, tile);
+            hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, Wg), dim3(kBlock), 0, sk, code, n, tab, ntiles, tile_hist, tmp_rec, q.w0, tile);
             BP_TRACE_SYNC(ctx, "k_coarse_scatter");
-            hipLaunchKernelGGL(k_fine_place, dim3(128, Wg), dim3(kBlock), 0, sk, tmp_code, tmp_idx, tab, ntiles, tile_hist, hsum + hist_blocks, count, cursor, idx, q.w0);
+            hipLaunchKernelGGL(k_fine_place, dim3(128, Wg), dim3(kBlock), 0, sk, tmp_rec, tab, ntiles, tile_hist, hsum + hist_blocks, count, cursor, idx, q.w0);
             BP_TRACE_SYNC(ctx, "k_fine_place");
             if (tm && k == 0) HIPCHK(hipEventRecord(ctx->ev[3], sk));
             // count[] = bucket starts, cursor[] = bucket ends.  Tasks of this group (bucket ids local to the group from here on):

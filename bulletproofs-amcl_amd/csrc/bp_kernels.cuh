@@ -122,10 +122,11 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
     for (uint32_t k = threadIdx.x; k < rows; k += kBlock) tile_hist[(size_t)k * ntiles + blockIdx.x] = lh[k];
 }
 
-// grid = (ntiles, W).  tile_off = scanned tile_hist.  Writes (code, point index) pairs grouped by coarse bin.
+// grid = (ntiles, W).  tile_off = scanned tile_hist.  Writes (code, point index) pairs grouped by coarse bin -- as ONE 8-byte record
+// per element: the kernel is bound by the address processing of its scattered stores (64 lanes, 64 different runs), and one
+// store instruction per element instead of two (2-byte code + 4-byte index) matters more than the 2 extra bytes.
 static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab, uint32_t ntiles,
-                                                                 const uint32_t* __restrict__ tile_off, uint16_t* __restrict__ tmp_code,
-                                                                 uint32_t* __restrict__ tmp_idx, int w0, uint32_t tile) {
+                                                                 const uint32_t* __restrict__ tile_off, uint2* __restrict__ tmp_rec, int w0, uint32_t tile) {
     __shared__ uint32_t lcur[128];
     const int w = w0 + (int)blockIdx.y;
     const int c = tab.cw[w], fb = tab.fbits[w];
@@ -141,8 +142,7 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
             int d = (int)raw - ((1 << (c - 1)) - 1);
             if (d != 0) {
                 uint32_t pos = atomicAdd(&lcur[((uint32_t)(d < 0 ? -d : d) - 1) >> fb], 1u);
-                tmp_code[pos] = (uint16_t)raw;
-                tmp_idx[pos] = (uint32_t)i;
+                tmp_rec[pos] = make_uint2((uint32_t)i, raw);
             }
         }
     }
@@ -151,8 +151,7 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
 // grid = (128, W); block (bin, w) owns the elements [tile_off[row * ntiles], tile_off[(row + 1) * ntiles]) of its
 // coarse bin (row = hoff[w] + bin; `total` closes the last row).  Two streaming passes over them: fine histogram,
 // then placement.  Writes start[g] / end[g] for its 2^fbits buckets and idx[] (point index + sign bit).
-static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint16_t* __restrict__ tmp_code, const uint32_t* __restrict__ tmp_idx, WinTab tab,
-                                                             uint32_t ntiles, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ total,
+static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __restrict__ tmp_rec, WinTab tab, uint32_t ntiles, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ total,
                                                              uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx, int w0) {
     __shared__ uint32_t lh[kBlock], lscan[kBlock / 64];
     const int w = w0 + (int)blockIdx.y;
@@ -166,7 +165,7 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint16_t* __
     lh[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-        int d = (int)tmp_code[j] - (int)half1;
+        int d = (int)tmp_rec[j].y - (int)half1;
         atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
     }
     __syncthreads();
@@ -180,9 +179,10 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint16_t* __
     lh[threadIdx.x] = ex;
     __syncthreads();
     for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-        int d = (int)tmp_code[j] - (int)half1;
+        const uint2 rec = tmp_rec[j];
+        int d = (int)rec.y - (int)half1;
         uint32_t pos = atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
-        idx[pos] = tmp_idx[j] | (d < 0 ? 0x80000000u : 0u);
+        idx[pos] = rec.x | (d < 0 ? 0x80000000u : 0u);
     }
 }
 
