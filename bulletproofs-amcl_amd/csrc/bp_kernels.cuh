@@ -60,6 +60,8 @@ struct WinTab {
 constexpr int kRecPerWin = 1;          // tail records per window handed to the host (record r carries weight 2^rpos[r], bp_capi.hip)
 
 constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane); larger MSMs use multiples (tile argument)
+constexpr int kDigitBatch = 4;         // scalars in flight per lane in k_digits_bin (tile / kBlock is a multiple of it)
+constexpr int kFineBatch = 8;          // records in flight per lane in k_fine_place
 constexpr int kMaxBinRows = 4096;      // sum over windows of coarse bins (c = 16: 16 x 128 per scalar set)
 
 // Signed-digit recoding without a serial carry: with k' = k + H, the raw cw-bit window w of k' equals
@@ -96,14 +98,23 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
     for (uint32_t k = threadIdx.x; k < rows; k += kBlock) lh[k] = 0;
     __syncthreads();
     size_t base = (size_t)blockIdx.x * tile;
+    const int wps = tab.W / tab.nsets;   // windows per scalar set (same geometry for every set)
 #pragma unroll 1
-    for (uint32_t e = 0; e < tile / kBlock; e++) {
-        size_t i = base + (size_t)e * kBlock + threadIdx.x;
-        if (i < n) {
-            const int wps = tab.W / tab.nsets;   // windows per scalar set (same geometry for every set)
-            for (int set = 0; set < tab.nsets; set++) {
+    for (uint32_t e0 = 0; e0 < tile / kBlock; e0 += kDigitBatch) {
+      // kDigitBatch scalars per lane are loaded before the first is recoded (the loop was paced by one 32-byte load per iteration)
+      for (int set = 0; set < tab.nsets; set++) {
+        ScalarWords sw[kDigitBatch];
+#pragma unroll
+        for (int u = 0; u < kDigitBatch; u++) {
+            size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
+            if (i < n) sw[u] = set ? scalars2[i] : scalars[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kDigitBatch; u++) {
+            size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
+            if (i < n) {
                 uint64_t q[4];
-                add256(q, set ? scalars2[i] : scalars[i], tab.bias);
+                add256(q, sw[u], tab.bias);
                 for (int w = set * wps; w < (set + 1) * wps; w++) {
                     int c = tab.cw[w];
                     uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);
@@ -117,6 +128,7 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
                 }
             }
         }
+      }
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < rows; k += kBlock) tile_hist[(size_t)k * ntiles + blockIdx.x] = lh[k];
@@ -134,15 +146,20 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
     for (uint32_t k = threadIdx.x; k < nbins; k += kBlock) lcur[k] = tile_off[(size_t)(tab.hoff[w] + k) * ntiles + blockIdx.x];
     __syncthreads();
     size_t base = (size_t)blockIdx.x * tile;
-#pragma unroll 4
-    for (uint32_t e = 0; e < tile / kBlock; e++) {
-        size_t i = base + (size_t)e * kBlock + threadIdx.x;
-        if (i < n) {
-            uint32_t raw = code[(size_t)w * n + i];
-            int d = (int)raw - ((1 << (c - 1)) - 1);
+    const uint32_t half1 = (1u << (c - 1)) - 1;
+    for (uint32_t e0 = 0; e0 < tile / kBlock; e0 += kFineBatch) {      // kFineBatch codes per lane in flight (tile is a multiple of 2048)
+        uint32_t raw[kFineBatch];
+#pragma unroll
+        for (int u = 0; u < kFineBatch; u++) {
+            size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
+            raw[u] = i < n ? code[(size_t)w * n + i] : half1;
+        }
+#pragma unroll
+        for (int u = 0; u < kFineBatch; u++) {
+            int d = (int)raw[u] - (int)half1;
             if (d != 0) {
                 uint32_t pos = atomicAdd(&lcur[((uint32_t)(d < 0 ? -d : d) - 1) >> fb], 1u);
-                tmp_rec[pos] = make_uint2((uint32_t)i, raw);
+                tmp_rec[pos] = make_uint2((uint32_t)(base + (size_t)(e0 + u) * kBlock + threadIdx.x), raw[u]);
             }
         }
     }
@@ -164,9 +181,17 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
     const uint32_t fmask = (1u << fb) - 1, half1 = (1u << (c - 1)) - 1;
     lh[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-        int d = (int)tmp_rec[j].y - (int)half1;
-        atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+    // kFineBatch records per lane are loaded before any of them is used: the loop is otherwise a chain of (load, LDS atomic) pairs
+    // paced by the load latency (32 dependent round trips per pass for an 8192-record bin)
+    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += kFineBatch * kBlock) {
+        uint32_t cd[kFineBatch];
+#pragma unroll
+        for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; cd[u] = j < hi ? tmp_rec[j].y : half1; }   // half1 = digit 0 = not an element
+#pragma unroll
+        for (int u = 0; u < kFineBatch; u++) {
+            int d = (int)cd[u] - (int)half1;
+            if (d != 0) atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+        }
     }
     __syncthreads();
     uint32_t cnt = lh[threadIdx.x], tot;
@@ -178,11 +203,18 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
     }
     lh[threadIdx.x] = ex;
     __syncthreads();
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-        const uint2 rec = tmp_rec[j];
-        int d = (int)rec.y - (int)half1;
-        uint32_t pos = atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
-        idx[pos] = rec.x | (d < 0 ? 0x80000000u : 0u);
+    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += kFineBatch * kBlock) {
+        uint2 rec[kFineBatch];
+#pragma unroll
+        for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; rec[u] = j < hi ? tmp_rec[j] : make_uint2(0u, half1); }
+#pragma unroll
+        for (int u = 0; u < kFineBatch; u++) {
+            int d = (int)rec[u].y - (int)half1;
+            if (d != 0) {
+                uint32_t pos = atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+                idx[pos] = rec[u].x | (d < 0 ? 0x80000000u : 0u);
+            }
+        }
     }
 }
 
