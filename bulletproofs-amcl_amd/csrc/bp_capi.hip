@@ -228,7 +228,11 @@ struct Impl {
 
         // Tile = scalars per block of the binning passes (BP_TILE: 2048 .. 16384 measured within 1 % of each other at 2^18 .. 2^22).
         static const uint32_t tile_env = getenv("BP_TILE") ? (uint32_t)atoi(getenv("BP_TILE")) : 0;
-        const uint32_t tile = tile_env ? tile_env : kTile;
+        // Below ~2^19 scalars a 2048-scalar tile leaves the per-scalar passes with a few dozen blocks for 256 CUs (n = 2^17: 65 blocks,
+        // k_digits_bin 71 us); the tile shrinks (never below one scalar per lane) until there are ~512 of them.
+        uint32_t tile = kTile;
+        while (tile > (uint32_t)kBlock && (n + tile - 1) / tile < 512) tile >>= 1;
+        if (tile_env) tile = tile_env;
         const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
         const uint32_t rows = tab.hoff[W];
         const size_t nhist = (size_t)rows * ntiles;

@@ -59,8 +59,9 @@ struct WinTab {
 };
 constexpr int kRecPerWin = 1;          // tail records per window handed to the host (record r carries weight 2^rpos[r], bp_capi.hip)
 
-constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane); larger MSMs use multiples (tile argument)
-constexpr int kDigitBatch = 4;         // scalars in flight per lane in k_digits_bin (tile / kBlock is a multiple of it)
+constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane) for large MSMs; smaller ones use smaller tiles
+                                       // (a multiple of kBlock) so that the passes still have a few hundred blocks (bp_capi.hip)
+constexpr int kDigitBatch = 4;         // scalars in flight per lane in k_digits_bin
 constexpr int kFineBatch = 8;          // records in flight per lane in k_fine_place
 constexpr int kMaxBinRows = 4096;      // sum over windows of coarse bins (c = 16: 16 x 128 per scalar set)
 
@@ -99,20 +100,21 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
     __syncthreads();
     size_t base = (size_t)blockIdx.x * tile;
     const int wps = tab.W / tab.nsets;   // windows per scalar set (same geometry for every set)
+    const uint32_t per = tile / kBlock;   // scalars per lane (tile is a multiple of kBlock)
 #pragma unroll 1
-    for (uint32_t e0 = 0; e0 < tile / kBlock; e0 += kDigitBatch) {
+    for (uint32_t e0 = 0; e0 < per; e0 += kDigitBatch) {
       // kDigitBatch scalars per lane are loaded before the first is recoded (the loop was paced by one 32-byte load per iteration)
       for (int set = 0; set < tab.nsets; set++) {
         ScalarWords sw[kDigitBatch];
 #pragma unroll
         for (int u = 0; u < kDigitBatch; u++) {
             size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
-            if (i < n) sw[u] = set ? scalars2[i] : scalars[i];
+            if (e0 + u < per && i < n) sw[u] = set ? scalars2[i] : scalars[i];
         }
 #pragma unroll
         for (int u = 0; u < kDigitBatch; u++) {
             size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
-            if (i < n) {
+            if (e0 + u < per && i < n) {
                 uint64_t q[4];
                 add256(q, sw[u], tab.bias);
                 for (int w = set * wps; w < (set + 1) * wps; w++) {
@@ -147,12 +149,13 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
     __syncthreads();
     size_t base = (size_t)blockIdx.x * tile;
     const uint32_t half1 = (1u << (c - 1)) - 1;
-    for (uint32_t e0 = 0; e0 < tile / kBlock; e0 += kFineBatch) {      // kFineBatch codes per lane in flight (tile is a multiple of 2048)
+    const uint32_t per = tile / kBlock;
+    for (uint32_t e0 = 0; e0 < per; e0 += kFineBatch) {      // kFineBatch codes per lane in flight
         uint32_t raw[kFineBatch];
 #pragma unroll
         for (int u = 0; u < kFineBatch; u++) {
             size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
-            raw[u] = i < n ? code[(size_t)w * n + i] : half1;
+            raw[u] = (e0 + u < per && i < n) ? code[(size_t)w * n + i] : half1;
         }
 #pragma unroll
         for (int u = 0; u < kFineBatch; u++) {
