@@ -23,6 +23,8 @@ def main():
     curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     lgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [6, 12]
     ctx = bp.Context(curve, 0)
+    if os.environ.get("TIME_IPP_C"):
+        ctx.set_window_bits(int(os.environ["TIME_IPP_C"]))       # window width for every MSM of the run (0 = the library's rule)
     for lg in lgs:
         n = 1 << lg
         Gv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, rs(n, 1), n))

@@ -189,6 +189,24 @@ def test_msm_full_size_linearity(bp, ctxs, name, lg):
     pts.free()
 
 
+@pytest.mark.parametrize("n", [513, 131071, 131073, 262145, 300001, 524287, 524289, 1048577])
+def test_msm_tile_boundaries_linearity(bp, ctxs, n):
+    """Sizes around the binning-tile switches (tile = 256 .. 2048 scalars per block, chosen so that ~512 blocks remain; ragged last
+    tiles; one element past a power of two): MSM(s, k.G) = (<s, k> mod r).G with the oracle's inner product, single and paired."""
+    ctx = ctxs["bls12_381"]
+    ks = O.random_scalars(ctx.curve, 31 + n, n)
+    s1 = O.random_scalars(ctx.curve, 32 + n, n)
+    s2 = O.random_scalars(ctx.curve, 33 + n, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    gen = O.generator(ctx.curve)
+    v1, v2 = bp.FieldElementVector.from_bytes(ctx, s1, n), bp.FieldElementVector.from_bytes(ctx, s2, n)
+    want1 = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, s1, n), gen)
+    want2 = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, s2, n), gen)
+    assert pts.multi_scalar_mul_var_time(v1) == want1
+    assert pts.multi_scalar_mul_pair(v1, v2) == (want1, want2)
+    pts.free()
+
+
 @pytest.mark.parametrize("n", [6000, 600, 2])     # 600 -> two shards of 300 terms: the single-launch small-MSM path
 @pytest.mark.parametrize("name", CURVES)
 def test_two_stage_sharded_msm(bp, ctxs, name, n):
