@@ -291,7 +291,7 @@ struct Impl {
             BP_TRACE_SYNC(ctx, "k_fine_place");
             if (tm && k == 0) HIPCHK(hipEventRecord(ctx->ev[3], sk));
             // count[] = bucket starts, cursor[] = bucket ends.  Tasks of this group (bucket ids local to the group from here on):
-            const unsigned bgrid = (unsigned)((q.nb + kBlock - 1) / kBlock);
+            const unsigned bgrid = (unsigned)((q.nb + kBlock * kTaskPer - 1) / (kBlock * kTaskPer));   // kTaskPer buckets per lane
             hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, sk, count + q.b0, cursor + q.b0, (uint32_t)q.nb, L, lshift, ntasks + q.b0, bins);
             hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, sk, bins, total_tasks);
             hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)q.scan_blocks), dim3(kBlock), 0, sk, ntasks + q.b0, q.nb, bsum);

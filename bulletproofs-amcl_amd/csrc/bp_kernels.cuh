@@ -305,24 +305,33 @@ constexpr uint32_t kLightMax = 8;   // buckets of 2..kLightMax tasks are summed 
 __device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = max(0, log2(L) - 7)
 
 // thread per bucket: ntasks[g], and a histogram of task lengths
+// kTaskPer buckets per lane: every block ends with one global atomic per occupied length bin, all blocks on the same ~129 words; with
+// one bucket per lane (2048 blocks at 2^19 buckets) that serialised traffic was most of the kernel's 30 us.
+constexpr int kTaskPer = 4;
 static __global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
                                                         uint32_t L, uint32_t lshift, uint32_t* __restrict__ ntasks, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t lh[kTaskBins];
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
     __syncthreads();
-    uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    if (g < nbuckets) {
-        uint32_t size = end[g] - start[g];
-        uint32_t full = size / L, rem = size % L;
-        ntasks[g] = full + (rem ? 1 : 0);
-        if (full) atomicAdd(&lh[0], full);
-        if (rem) atomicAdd(&lh[task_bin(rem, L, lshift)], 1u);
+    uint32_t sz[kTaskPer];
+#pragma unroll
+    for (int u = 0; u < kTaskPer; u++) {
+        uint32_t g = (blockIdx.x * kTaskPer + u) * kBlock + threadIdx.x;
+        sz[u] = g < nbuckets ? end[g] - start[g] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kTaskPer; u++) {
+        uint32_t g = (blockIdx.x * kTaskPer + u) * kBlock + threadIdx.x;
+        if (g < nbuckets) {
+            uint32_t full = sz[u] / L, rem = sz[u] % L;
+            ntasks[g] = full + (rem ? 1 : 0);
+            if (full) atomicAdd(&lh[0], full);
+            if (rem) atomicAdd(&lh[task_bin(rem, L, lshift)], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) if (lh[b]) atomicAdd(&bin_count[b], lh[b]);
 }
-
-// single block: bin_count -> exclusive offsets (in place); total task count -> *total
 static __global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __restrict__ bin, uint32_t* __restrict__ total) {
     __shared__ uint32_t lds[kBlock / 64];
     static_assert(kTaskBins <= kBlock, "one thread per bin");
@@ -343,37 +352,44 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
     __shared__ uint32_t lh[kTaskBins], lbase[kTaskBins];
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
     __syncthreads();
-    uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t size = 0, s0 = 0, toff = 0, nfull = 0, rem = 0, rank_full = 0, rank_rem = 0, bin_rem = 0;
-    if (g < nbuckets) {
-        s0 = start[g];
-        size = end[g] - s0;
-        toff = task_off[g];
-        nfull = size / L;                              // tasks of exactly L points (bin 0), ranked inside the block
-        rem = size % L;                                // plus one shorter task
-        if (nfull) rank_full = atomicAdd(&lh[0], nfull);
-        if (rem) { bin_rem = task_bin(rem, L, lshift); rank_rem = atomicAdd(&lh[bin_rem], 1u); }
+    uint32_t size[kTaskPer], s0[kTaskPer], toff[kTaskPer], rank_full[kTaskPer], rank_rem[kTaskPer];
+#pragma unroll
+    for (int u = 0; u < kTaskPer; u++) {
+        uint32_t g = (blockIdx.x * kTaskPer + u) * kBlock + threadIdx.x;
+        size[u] = 0; s0[u] = 0; toff[u] = 0; rank_full[u] = 0; rank_rem[u] = 0;
+        if (g < nbuckets) { s0[u] = start[g]; size[u] = end[g] - s0[u]; toff[u] = task_off[g]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kTaskPer; u++) {
+        const uint32_t nfull = size[u] / L, rem = size[u] % L;   // nfull tasks of exactly L points (bin 0), ranked inside the block, plus one shorter
+        if (nfull) rank_full[u] = atomicAdd(&lh[0], nfull);
+        if (rem) rank_rem[u] = atomicAdd(&lh[task_bin(rem, L, lshift)], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lbase[b] = lh[b] ? atomicAdd(&bin_cursor[b], lh[b]) : 0;
     __syncthreads();
-    if (size == 0) return;
-    for (uint32_t k = 0; k < nfull; k++) {
-        order[lbase[0] + rank_full + k] = toff + k;
-        t_start[toff + k] = s0 + k * L;
-        t_len[toff + k] = L;
-    }
-    if (rem) {
-        order[lbase[bin_rem] + rank_rem] = toff + nfull;
-        t_start[toff + nfull] = s0 + nfull * L;
-        t_len[toff + nfull] = rem;
-    }
-    const uint32_t nt = nfull + (rem ? 1u : 0u);
-    if (nt > kLightMax) {
-        heavy[atomicAdd(nheavy, 1u)] = g;
-        const uint32_t nch = (nt + kBlock - 1) / kBlock;          // chunks of kBlock task sums for k_combine_chunks
-        const uint32_t base = atomicAdd(nchunks, nch);
-        for (uint32_t j = 0; j < nch; j++) chunks[base + j] = make_uint2(g, j);
+#pragma unroll
+    for (int u = 0; u < kTaskPer; u++) {
+        if (size[u] == 0) continue;
+        const uint32_t g = (blockIdx.x * kTaskPer + u) * kBlock + threadIdx.x;
+        const uint32_t nfull = size[u] / L, rem = size[u] % L;
+        for (uint32_t k = 0; k < nfull; k++) {
+            order[lbase[0] + rank_full[u] + k] = toff[u] + k;
+            t_start[toff[u] + k] = s0[u] + k * L;
+            t_len[toff[u] + k] = L;
+        }
+        if (rem) {
+            order[lbase[task_bin(rem, L, lshift)] + rank_rem[u]] = toff[u] + nfull;
+            t_start[toff[u] + nfull] = s0[u] + nfull * L;
+            t_len[toff[u] + nfull] = rem;
+        }
+        const uint32_t nt = nfull + (rem ? 1u : 0u);
+        if (nt > kLightMax) {
+            heavy[atomicAdd(nheavy, 1u)] = g;
+            const uint32_t nch = (nt + kBlock - 1) / kBlock;          // chunks of kBlock task sums for k_combine_chunks
+            const uint32_t base = atomicAdd(nchunks, nch);
+            for (uint32_t j = 0; j < nch; j++) chunks[base + j] = make_uint2(g, j);
+        }
     }
 }
 
