@@ -678,7 +678,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->fixed_base_table.release();
-    for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_code, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
+    for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
                       &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags}) b->release();
     if (ctx->pool) ctx->pool->release();     // cached blocks go back to the driver; live handles keep the pool itself alive
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);

@@ -150,7 +150,7 @@ struct bp_ctx {
     // MSM workspace
     DevBuf fixed_base_table;            // d * 2^(4j) * G, built on first use (bp_g1vec_fixed_base_mul)
     bool fixed_base_ready = false;
-    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_code, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch;
+    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     hipEvent_t ev[8] = {};
