@@ -111,25 +111,29 @@ struct R1cs {
         uint8_t* out3[3] = {P3, P3 + pb, P3 + 2 * pb};
         return commit_vectors_concurrent(ctx, GHh, sc3, out3, 3);
     }
-    // k <= 3 independent commitments over the same [G | H | h]: all in flight at once, on the context and its two siblings (the
+    // k independent MSMs over the same point vector, three in flight at a time: on the context and its two siblings (the
     // latency-bound bucket reduce and host tail of one hide behind the accumulate of the others).  Every MSM that was begun is
     // ended before returning, whatever failed, because the vectors in T are released on return.
-    static int commit_vectors_concurrent(bp_ctx* ctx, const bp_g1vec* GHh, bp_frvec* const sc[], uint8_t* const out_le[], int k) {
+    static int commit_vectors_concurrent(bp_ctx* ctx, const bp_g1vec* pts, bp_frvec* const sc[], uint8_t* const out_le[], int k) {
         bp_ctx* ex[3] = {ctx, bp_internal_helper(ctx, 0), bp_internal_helper(ctx, 1)};
-        if (k > 3 || !ex[1] || !ex[2]) { for (int i = 0; i < k; i++) RC(bp_msm_g1(ctx, GHh, sc[i], out_le[i])); return BP_OK; }
-        int rc = BP_OK, begun = 0;
-        for (int i = 0; i < k && rc == BP_OK; i++) {
-            if (i > 0) rc = bp_internal_fork(ctx, ex[i]);
-            if (rc == BP_OK) rc = bp_msm_g1_begin(ex[i], GHh, sc[i]);
-            if (rc == BP_OK) begun++;
+        if (!ex[1] || !ex[2]) { for (int i = 0; i < k; i++) RC(bp_msm_g1(ctx, pts, sc[i], out_le[i])); return BP_OK; }
+        int rc = BP_OK;
+        for (int i0 = 0; i0 < k && rc == BP_OK; i0 += 3) {
+            const int kb = k - i0 < 3 ? k - i0 : 3;
+            int begun = 0;
+            for (int i = 0; i < kb && rc == BP_OK; i++) {
+                if (i > 0) rc = bp_internal_fork(ctx, ex[i]);
+                if (rc == BP_OK) rc = bp_msm_g1_begin(ex[i], pts, sc[i0 + i]);
+                if (rc == BP_OK) begun++;
+            }
+            // the host tails (~0.13 ms each) on the siblings' helper threads beside this one
+            int r_end[3] = {BP_OK, BP_OK, BP_OK};
+            bool queued[3] = {false, false, false};
+            for (int i = 1; i < begun; i++) queued[i] = ex[i]->worker.submit([&, i]() { r_end[i] = bp_msm_g1_end(ex[i], out_le[i0 + i]); });
+            for (int i = 0; i < begun; i++) if (!queued[i]) r_end[i] = bp_msm_g1_end(ex[i], out_le[i0 + i]);
+            for (int i = 1; i < begun; i++) if (queued[i]) ex[i]->worker.wait();
+            for (int i = 0; i < begun; i++) if (rc == BP_OK) rc = r_end[i];
         }
-        // the three host tails (~0.13 ms each) on the siblings' helper threads beside this one
-        int r_end[3] = {BP_OK, BP_OK, BP_OK};
-        bool queued[3] = {false, false, false};
-        for (int i = 1; i < begun; i++) queued[i] = ex[i]->worker.submit([&, i]() { r_end[i] = bp_msm_g1_end(ex[i], out_le[i]); });
-        for (int i = 0; i < begun; i++) if (!queued[i]) r_end[i] = bp_msm_g1_end(ex[i], out_le[i]);
-        for (int i = 1; i < begun; i++) if (queued[i]) ex[i]->worker.wait();
-        for (int i = 0; i < begun; i++) if (rc == BP_OK) rc = r_end[i];
         return rc;
     }
 
@@ -214,11 +218,20 @@ struct R1cs {
         memcpy(gh.data() + pb, h_le, pb);
         const int tk[5] = {1, 3, 4, 5, 6};
         static const char* const tlabel[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
-        for (int j = 0; j < 5; j++) {                                                                          // :496-500
-            std::vector<uint8_t> sc(64);
-            fr_out<F>(tc[tk[j]], sc.data());
-            fr_out<F>(tb[tk[j]], sc.data() + 32);
-            RC(small_msm(ctx, T, gh, sc, pb, P + (6 + j) * pb));
+        {   // T_k = t_k g + t_k_blinding h, k = 1, 3, 4, 5, 6 (:496-500): five independent two-term commitments, three in flight at a time
+            bp_g1vec* ghv = nullptr;
+            RC(bp_g1vec_upload(ctx, gh.data(), 2, BP_FMT_LE, &ghv));
+            T.keep(ghv);
+            bp_frvec* tsc[5] = {};
+            uint8_t* tout[5] = {};
+            for (int j = 0; j < 5; j++) {
+                std::vector<uint8_t> sc(64);
+                fr_out<F>(tc[tk[j]], sc.data());
+                fr_out<F>(tb[tk[j]], sc.data() + 32);
+                RC(upload_scalars(ctx, T, sc, &tsc[j]));
+                tout[j] = P + (6 + j) * pb;
+            }
+            RC(commit_vectors_concurrent(ctx, ghv, tsc, tout, 5));
         }
         for (int j = 0; j < 5; j++) RC(bp_transcript_commit_point(t, cv, tlabel[j], P + (6 + j) * pb));
         const Fe<F> u = challenge(t, cv, "u"), x = challenge(t, cv, "x");
