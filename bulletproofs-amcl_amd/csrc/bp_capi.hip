@@ -257,7 +257,6 @@ struct Impl {
         BP_TRACE_SYNC(ctx, "k_digits_bin");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, hsum);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, hsum, hist_blocks);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, hsum, tile_hist, (uint32_t*)nullptr);
         BP_TRACE_SYNC(ctx, "scan tile_hist");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
@@ -295,7 +294,6 @@ struct Impl {
             hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, sk, count + q.b0, cursor + q.b0, (uint32_t)q.nb, L, lshift, ntasks + q.b0, bins);
             hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, sk, bins, total_tasks);
             hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)q.scan_blocks), dim3(kBlock), 0, sk, ntasks + q.b0, q.nb, bsum);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, sk, bsum, q.scan_blocks);
             hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)q.scan_blocks), dim3(kBlock), 0, sk, ntasks + q.b0, q.nb, bsum, task_off + q.b0, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, sk, count + q.b0, cursor + q.b0, (uint32_t)q.nb, L, lshift, task_off + q.b0, bins, order, t_start, t_len,
                                heavy, nheavy, chunks, nchunks);

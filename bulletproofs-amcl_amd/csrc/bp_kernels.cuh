@@ -256,38 +256,28 @@ static __global__ void __launch_bounds__(kBlock) k_scan_block_sums(const uint32_
 }
 
 // single block: exclusive scan of the block sums, in place; block_sums[nblocks] receives the grand total
-static __global__ void __launch_bounds__(kBlock) k_scan_top(uint32_t* __restrict__ block_sums, size_t nblocks) {
-    __shared__ uint32_t lds[kBlock / 64];
-    uint32_t carry = 0;
-    for (size_t chunk = 0; chunk < nblocks; chunk += kScanPerBlock) {
-        size_t base = chunk + (size_t)threadIdx.x * kScanPerThread;
-        uint32_t v[kScanPerThread], s = 0;
-#pragma unroll
-        for (int j = 0; j < kScanPerThread; j++) { v[j] = base + j < nblocks ? block_sums[base + j] : 0; s += v[j]; }
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan(s, lds, tot) + carry;
-#pragma unroll
-        for (int j = 0; j < kScanPerThread; j++) { if (base + j < nblocks) block_sums[base + j] = ex; ex += v[j]; }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) block_sums[nblocks] = carry;   // grand total, one slot past the block sums
-}
-
-// out[i] = exclusive prefix of in; optionally also writes a copy (the scatter cursors).  in/out may alias.
-static __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in, size_t n, const uint32_t* __restrict__ block_sums,
+// The second level of the scan is folded into this kernel: block b sums the b block totals before it (a few hundred to a few
+// thousand words) instead of reading a pre-scanned array -- one launch fewer per scan, and these launches are ~5 us each on a path
+// that is a few hundred microseconds long for the MSMs of an IPP round.  The last block leaves the grand total in block_sums[nblocks].
+static __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in, size_t n, uint32_t* __restrict__ block_sums,
                                                         uint32_t* out, uint32_t* __restrict__ out_copy) {
     __shared__ uint32_t lds[kBlock / 64];
+    uint32_t before = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) before += block_sums[b];
+    uint32_t prefix;
+    block_exclusive_scan(before, lds, prefix);                    // prefix = sum of the totals of blocks 0 .. blockIdx.x - 1
     size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread], s = 0;
 #pragma unroll
     for (int j = 0; j < kScanPerThread; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
     uint32_t tot;
-    uint32_t ex = block_exclusive_scan(s, lds, tot) + block_sums[blockIdx.x];
+    uint32_t ex = block_exclusive_scan(s, lds, tot) + prefix;
 #pragma unroll
     for (int j = 0; j < kScanPerThread; j++) {
         if (base + j < n) { out[base + j] = ex; if (out_copy) out_copy[base + j] = ex; }
         ex += v[j];
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) block_sums[gridDim.x] = prefix + tot;
 }
 
 // ---------------------------------------------------------------------------------------------- tasks
