@@ -311,7 +311,7 @@ struct Impl {
             if (tm && k == G - 1) HIPCHK(hipEventRecord(ctx->ev[5], sk));
             hipStream_t tk = sk;
             if (G > 1) { tk = ctx->tail_stream[k]; HIPCHK(hipStreamWaitEvent(tk, ctx->ev_acc[2 * k + 1], 0)); }
-            hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(q.max_chunks < 1024 ? q.max_chunks : 1024)), dim3(kBlock), 0, tk, chunks, nchunks, task_off + q.b0, ntasks + q.b0, tsum);
+            hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(q.max_chunks < 256 ? q.max_chunks : 256)), dim3(kBlock), 0, tk, chunks, nchunks, task_off + q.b0, ntasks + q.b0, tsum);
             hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)(q.max_heavy < 256 ? q.max_heavy : 256)), dim3(kBlock), 0, tk, heavy, nheavy, task_off + q.b0, ntasks + q.b0, tsum);
             BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
             hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tab.rboff[q.w1] - tab.rboff[q.w0]), dim3(kBlock), 0, tk, tsum, task_off, ntasks, tab, (uint32_t)tab.rboff[q.w0], partial);
