@@ -121,8 +121,14 @@ struct Ipp {
         auto* a = (ScalarWords*)st->a; auto* b = (ScalarWords*)st->b;
         auto* cLR = (ScalarWords*)st->cLR;
         int rc;
-        if ((rc = inner(ctx, a, b + h, h, (ScalarWords*)st->partial, cLR))) return rc;          // c_L = <a_L, b_R>
-        if ((rc = inner(ctx, a + h, b, h, (ScalarWords*)st->partial, cLR + 1))) return rc;      // c_R = <a_R, b_L>
+        {   // c_L = <a_L, b_R>, c_R = <a_R, b_L> (src/ipp.rs:77-78, 145-146): both in one launch pair
+            unsigned g = blocks_for(h);
+            if (g > kInnerBlocks / 2) g = kInnerBlocks / 2;
+            if (g == 0) g = 1;
+            hipLaunchKernelGGL(k_fr_inner2<C>, dim3(g, 2), dim3(kBlock), 0, ctx->stream, a, b + h, a + h, b, h, (ScalarWords*)st->partial);
+            hipLaunchKernelGGL(k_fr_inner2_final<C>, dim3(2), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)st->partial, g, cLR);
+            HIPCHK(hipGetLastError());
+        }
         if (!st->fold_generators) {
             size_t m = 2 * st->n0 + 1;
             hipLaunchKernelGGL(k_ipp_round_scalars<C>, dim3(blocks_for(st->n0)), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG,

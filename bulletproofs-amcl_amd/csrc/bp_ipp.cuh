@@ -64,6 +64,31 @@ __global__ void __launch_bounds__(kBlock) k_fr_inner_final(const ScalarWords* __
     if (threadIdx.x == 0) fr_store<F>(out, 0, fe_to_mont<F>(acc));
 }
 
+// Two inner products of the same length in one launch pair (c_L = <a_lo, b_hi> and c_R = <a_hi, b_lo> of an IPP round,
+// src/ipp.rs:77-78): blockIdx.y selects the pair; partial holds gridDim.x sums per product; out[0], out[1].
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_inner2(const ScalarWords* __restrict__ a0, const ScalarWords* __restrict__ b0, const ScalarWords* __restrict__ a1,
+                                                      const ScalarWords* __restrict__ b1, size_t n, ScalarWords* __restrict__ partial) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    const ScalarWords* a = blockIdx.y ? a1 : a0;
+    const ScalarWords* b = blockIdx.y ? b1 : b0;
+    Fe<F> acc = fe_zero<F>();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc = fe_add(acc, fe_mul(fr_load<F>(a, i), fr_load<F>(b, i)));
+    acc = block_fr_sum<F>(acc, lds);
+    if (threadIdx.x == 0) fr_store<F>(partial, (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
+}
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_fr_inner2_final(const ScalarWords* __restrict__ partial, uint32_t m, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) acc = fe_add(acc, fr_load<F>(partial, (size_t)blockIdx.x * m + i));
+    acc = block_fr_sum<F>(acc, lds);
+    if (threadIdx.x == 0) fr_store<F>(out, blockIdx.x, fe_to_mont<F>(acc));
+}
+
 // out[i] = a[i] * b[i]   (FieldElementVector::hadamard_product)
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_fr_hadamard(const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b, size_t n,
