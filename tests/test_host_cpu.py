@@ -47,6 +47,16 @@ def test_transcript_protocol_matches_oracle(bp, golden, name):
         mb = 48 if cid == 0 else 32
         t2.append_message(b"t_x", int.from_bytes(s, "little").to_bytes(mb, "big"))       # FieldElement::to_bytes
         assert t1.challenge_bytes(b"c", 40) == t2.challenge_bytes(b"c", 40)
+    # bp_transcript_commit_points(n) = n commit_point calls with the same label (the V commitments of a statement), oracle beside it
+    t3, t4, t5 = bp.Transcript(b"r1cs"), bp.Transcript(b"r1cs"), O.Transcript(b"r1cs")
+    t3.commit_points(cid, b"V", b"".join(pts), len(pts))
+    for p in pts:
+        t4.commit_point(cid, b"V", p)
+        t5.commit_point(cid, b"V", p)
+    z3, z4, z5 = t3.challenge_scalar(cid, b"z"), t4.challenge_scalar(cid, b"z"), t5.challenge_scalar(cid, b"z")
+    assert z3 == z4 == z5
+    t3.commit_points(cid, b"V", b"", 0)                                                   # no points: nothing absorbed
+    assert t3.challenge_scalar(cid, b"y") == t4.challenge_scalar(cid, b"y")
 
 
 @pytest.mark.parametrize("name", ["bls12_381", "bn254"])
