@@ -28,14 +28,14 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
         while (((size_t)1 << (lg + 1)) <= n) lg++;
         c = lg - 1;   // measured (scripts/time_msm.py sweeps): short per-bucket chains beat fewer buckets up to c = 16
         if (c > 16) c = 16;
-        // ... unless that leaves > 2^17 nearly empty buckets (the bucket reduce costs ~2 ns per bucket whatever they
+        // ... unless that leaves > 2^14 nearly empty buckets (the bucket reduce costs ~2 ns per bucket whatever they
         // hold): shrink c until the mean occupancy reaches 8.  nnz = non-zero scalars per set when the caller knows
         // it (the IPP rounds: half of the generators carry a zero), else n.  (scripts/sweep_ipp_c.py)
         const size_t live = nnz ? nnz : n;
         while (c > 8 && nsets > 1) {   // measured for the paired (IPP round) shape only; single-set sweeps favour lg n - 1 throughout
             uint64_t W1 = (uint64_t)((fr_bits + 1 + c - 1) / c);
             uint64_t buckets = (uint64_t)nsets * W1 << (c - 1), entries = (uint64_t)nsets * W1 * live;
-            if (buckets <= (1u << 17) || entries >= 8 * buckets) break;
+            if (buckets <= (1u << 14) || entries >= 8 * buckets) break;   // floor 2^14 (2^17 until round 2: n = 2^12, 2^13 ran 4-7 % slower at c = 12)
             c--;
         }
     }
