@@ -302,6 +302,34 @@ template <class C, class M = MulInline> BP_HD void xyzz_lazy_add_aff(XyzzLazy<C>
     a.y = Y3;
 }
 
+// The same addition for the inner loop of k_accumulate: the accumulator is known to hold a finite point, q is finite and arrives
+// as bounded limbs (x canonical, y < 2p: the negation of a canonical y is p - y, no add-back pass).  Single path: when q.x equals
+// the accumulator's x (doubling or cancellation) it returns false with the accumulator UNTOUCHED and the caller takes the general
+// function above for that one point -- so the loop around this function has no merge of several definitions of the accumulator
+// (the general form cost ~140 register copies per iteration at the loop's phi nodes).  X3 is one pass
+// R^2 - PPP - 2Q + 6p instead of three subtractions.
+template <class C, class M = MulInline>
+BP_HD bool xyzz_lazy_add_aff_fast(XyzzLazy<C>& a, const FeB<typename C::Fp, 1>& qx, const FeB<typename C::Fp, 2>& qy) {
+    using Fp = typename C::Fp;
+    FeB<Fp, 2> U2 = M::mul(qx, a.zz);
+    FeB<Fp, 2> S2 = M::mul(qy, a.zzz);
+    FeB<Fp, 10> Pp = feb_sub<8>(U2, a.x);
+    FeB<Fp, 6> Rr = feb_sub<4>(S2, a.y);
+    if (feb_is_zero_mod_p(Pp)) return false;
+    FeB<Fp, 2> PP = M::sqr(Pp);
+    FeB<Fp, 2> PPP = M::mul(Pp, PP);
+    FeB<Fp, 2> Q = M::mul(a.x, PP);
+    FeB<Fp, 2> R2 = M::sqr(Rr);
+    FeB<Fp, 8> X3 = feb_sub2k<6>(R2, PPP, feb_add(Q, Q));
+    FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
+    FeB<Fp, 4> Y3 = feb_widen<4>(M::mul_add_mul(Rr, QX, feb_neg<4>(a.y), PPP));
+    a.zz = M::mul(a.zz, PP);
+    a.zzz = M::mul(a.zzz, PPP);
+    a.x = X3;
+    a.y = Y3;
+    return true;
+}
+
 // ----------------------------------------------------------------------------------------------- lazy full addition / doubling
 // The same bounded domain for bucket-sum + bucket-sum additions (tree sums, the digit-sum reduce, the small-MSM path):
 //     X < 8p,  Y < 4p,  ZZ < 2p,  ZZZ < 2p   on both operands and on the result.

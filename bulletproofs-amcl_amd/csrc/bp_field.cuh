@@ -239,6 +239,125 @@ template <class P> BP_HD Fe<P> fe_dbl(const Fe<P>& a) { return fe_add<P>(a, a); 
 #define BP_OPAQUE_ONE(one) ((void)0)
 #endif
 
+// ----------------------------------------------------------------------------------------------- fused Montgomery core
+// Round 3.  The product a*b and the reduction m*p are accumulated in the SAME 64-bit column wherever that provably fits, so a
+// column costs one limb extraction (and + 64-bit shift) instead of two plus the "t[k] * 1" re-injection of the two-pass form:
+//     column k:  acc = carry + sum_{i+j=k} a_i b_j + sum_{i<k} m_i p_{k-i};   m_k = acc * (-p^-1) mod 2^30;   acc += m_k p_0;   acc >>= 30
+// Round 2 rejected this ("26 products of 30x30 bits overflow 64 bits"), which is the bound for a column with 13 + 13 FULL-SIZE
+// terms.  The real bound is smaller: column k < N has k+1 terms of each kind, and the m*p terms are m_i (< 2^30) times the ACTUAL
+// limbs of p (on average half as large).  Evaluated at compile time below (worst-case operand limbs, the modulus' own limbs):
+// for the 381-bit Fp only columns 10, 11, 12 of 26 exceed 2^64; for the 9-limb fields (BN254 Fp, both Fr) NO column does.
+// The few middle columns that do not fit run as two chains (product chain + reduction chain, exactly the two-pass arithmetic)
+// and the chains are joined by one 64-bit addition.  Per 381-bit product: 23 x (mad + and + shift) - 1 add fewer.
+// Same value as the two-pass form in every case: (a b [+ t1] + m p) / R with the same m.
+template <class P>
+struct Fuse {
+    static constexpr int N = P::NL;
+    // largest top limb of a normalised value < 32 p (the widest bound FeB allows)
+    static constexpr uint64_t top_limb_bound() {
+        uint32_t t[N] = {};
+        for (int k = 0; k < 32; k++) {                       // t = 32 p by repeated addition, limbs normalised except the top one
+            uint32_t carry = 0;
+            for (int i = 0; i < N; i++) { uint64_t x = (uint64_t)t[i] + P::C.mod[i] + carry; if (i < N - 1) { carry = (uint32_t)(x >> LB); t[i] = (uint32_t)x & LMASK; } else t[i] = (uint32_t)x; }
+        }
+        return t[N - 1];
+    }
+    static constexpr bool fits(int k) {
+        const uint64_t top = top_limb_bound();
+        unsigned __int128 tot = (unsigned __int128)1 << 36;          // carry in (< 2^34), an injected limb (< 2^31), slack
+        for (int i = 0; i < N; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= N) continue;
+            const uint64_t ai = i == N - 1 ? top : (uint64_t)LMASK, bj = j == N - 1 ? top : (uint64_t)LMASK;
+            tot += (unsigned __int128)ai * bj;                        // a_i b_j (a doubled cross term of a square is two of these)
+            tot += (unsigned __int128)LMASK * P::C.mod[j];            // m_i p_j
+        }
+        return tot < ((unsigned __int128)1 << 64);
+    }
+    static constexpr int lo() { for (int k = 0; k < 2 * N; k++) if (!fits(k)) return k; return 2 * N; }          // first column that does not fit
+    static constexpr int hi() { for (int k = 2 * N - 1; k >= 0; k--) if (!fits(k)) return k; return -1; }       // last one
+    static_assert(top_limb_bound() <= LMASK, "32 p must fit the limb vector");
+};
+
+// a*b terms of column k into acc.  SQR: b is ignored, a2 = 2a (cross terms once against the doubled operand).
+// (Loops are written with exact bounds: a full-range loop with a condition inside blows the unroller's size budget before the
+// outer column loop is unrolled and k becomes a constant.)
+template <class P, bool SQR, bool PIN> BP_HD void mont_ab_terms(uint64_t& acc, const int k, const uint32_t* a, const uint32_t* b, const uint32_t* a2) {
+    constexpr int N = P::NL;
+    if (SQR) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) { acc += (uint64_t)a2[i] * a[k - i]; if (PIN) BP_KEEP_ORDER(acc); }
+        if ((k & 1) == 0 && k / 2 < N) { acc += (uint64_t)a[k / 2] * a[k / 2]; if (PIN) BP_KEEP_ORDER(acc); }
+    } else {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) { acc += (uint64_t)a[i] * b[k - i]; if (PIN) BP_KEEP_ORDER(acc); }
+    }
+}
+// m*p terms of column k that involve ALREADY KNOWN m (i < k for k < N; i = k-N+1 .. N-1 above)
+template <class P, bool PIN> BP_HD void mont_mp_terms(uint64_t& acc, const int k, const uint32_t* m) {
+    constexpr int N = P::NL;
+#pragma unroll
+    for (int i = (k < N ? 0 : k - N + 1); i < (k < N ? k : N); i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; if (PIN) BP_KEEP_ORDER(acc); }
+}
+// one fused column: everything into acc, then m_k (k < N) or the result limb (k >= N), then the carry
+template <class P, bool SQR, bool ADD, bool PIN>
+BP_HD void mont_fused_column(uint64_t& acc, const int k, const uint32_t* a, const uint32_t* b, const uint32_t* a2, const uint32_t* t1, uint32_t one, uint32_t* m, uint32_t* r) {
+    constexpr int N = P::NL;
+    mont_ab_terms<P, SQR, PIN>(acc, k, a, b, a2);
+    if (ADD) { acc += (uint64_t)t1[k] * one; if (PIN) BP_KEEP_ORDER(acc); }
+    mont_mp_terms<P, PIN>(acc, k, m);
+    if (k < N) {
+        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
+        { acc += (uint64_t)m[k] * P::C.mod[0]; if (PIN) BP_KEEP_ORDER(acc); }
+    } else {
+        r[k - N] = (uint32_t)acc & LMASK;
+    }
+    acc >>= LB;
+}
+
+// r = (a b [+ t1] + m p) / R, limbs normalised, NO final subtraction (value < a b / R + t1 / R + p).
+//   SQR  a*a with 91 instead of 169 product terms          ADD  t1 = 2N limbs (each < 2^31) added to the product
+//   PIN  pin the order of every mad chain (BP_KEEP_ORDER; the lazy multipliers) or leave it to the compiler (strict functions)
+template <class P, bool SQR, bool ADD, bool PIN> BP_HD void mont_core(const uint32_t* a, const uint32_t* b, const uint32_t* t1, uint32_t* r) {
+    constexpr int N = P::NL;
+    constexpr bool kSplit = Fuse<P>::lo() <= Fuse<P>::hi();
+    constexpr int LO = kSplit ? Fuse<P>::lo() : 2 * N, HI = kSplit ? Fuse<P>::hi() : 2 * N - 1;   // no middle block: the first loop runs over every column
+    uint32_t a2[N];
+    if (SQR) {
+#pragma unroll
+        for (int i = 0; i < N; i++) a2[i] = a[i] << 1;
+    }
+    uint32_t m[N];
+    uint32_t one = 1;
+    if (ADD || kSplit) BP_OPAQUE_ONE(one);
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < LO; k++) mont_fused_column<P, SQR, ADD, PIN>(acc, k, a, b, a2, t1, one, m, r);
+    if (kSplit) {
+        // ---- middle block: product chain stays in acc, reduction chain in accB (the two-pass arithmetic) ----
+        uint64_t accB = 0;
+#pragma unroll
+        for (int q = LO; q <= HI; q++) {
+            mont_ab_terms<P, SQR, PIN>(acc, q, a, b, a2);
+            if (ADD) { acc += (uint64_t)t1[q] * one; if (PIN) BP_KEEP_ORDER(acc); }
+            const uint32_t tq = (uint32_t)acc & LMASK;
+            acc >>= LB;
+            { accB += (uint64_t)tq * one; if (PIN) BP_KEEP_ORDER(accB); }
+            mont_mp_terms<P, PIN>(accB, q, m);
+            if (q < N) {
+                m[q] = ((uint32_t)accB * P::C.inv) & LMASK;
+                { accB += (uint64_t)m[q] * P::C.mod[0]; if (PIN) BP_KEEP_ORDER(accB); }
+            } else {
+                r[q - N] = (uint32_t)accB & LMASK;
+            }
+            accB >>= LB;
+        }
+        acc += accB;                                           // both carries enter column HI + 1
+#pragma unroll
+        for (int k = HI + 1; k < 2 * N; k++) mont_fused_column<P, SQR, ADD, PIN>(acc, k, a, b, a2, t1, one, m, r);
+    }
+}
+
 // Montgomery reduction of 2*NL normalised limbs t (value < p * R) -> t / R mod p, product scanning.
 template <class P> BP_HD Fe<P> fe_mont_reduce(const uint32_t* t) {
     constexpr int N = P::NL;
@@ -266,41 +385,20 @@ template <class P> BP_HD Fe<P> fe_mont_reduce(const uint32_t* t) {
     return r;
 }
 
-// Montgomery product a*b/R mod p.
+// Montgomery product a*b/R mod p (fused core, compiler-scheduled chains).
 template <class P> BP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
-    constexpr int N = P::NL;
-    uint32_t t[2 * N];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N - 1; k++) {
-#pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) acc += (uint64_t)a.v[i] * b.v[k - i];
-        t[k] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
-    t[2 * N - 1] = (uint32_t)acc;
-    return fe_mont_reduce<P>(t);
+    Fe<P> r;
+    mont_core<P, false, false, false>(a.v, b.v, nullptr, r.v);
+    fe_cond_sub_p<P>(r.v);   // a b / R + p < 2p
+    return r;
 }
 
-// Montgomery square: cross products taken once against a doubled operand (2 a_i < 2^31; a column of
-// <= 6 doubled cross terms + 1 square stays below 2^64).
+// Montgomery square: cross products taken once against a doubled operand (2 a_i < 2^31).
 template <class P> BP_HD Fe<P> fe_sqr(const Fe<P>& a) {
-    constexpr int N = P::NL;
-    uint32_t a2[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) a2[i] = a.v[i] << 1;
-    uint32_t t[2 * N];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N - 1; k++) {
-#pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
-        t[k] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
-    t[2 * N - 1] = (uint32_t)acc;
-    return fe_mont_reduce<P>(t);
+    Fe<P> r;
+    mont_core<P, true, false, false>(a.v, a.v, nullptr, r.v);
+    fe_cond_sub_p<P>(r.v);
+    return r;
 }
 
 template <class P> BP_HD Fe<P> fe_to_mont(const Fe<P>& raw) {
@@ -390,6 +488,22 @@ constexpr LazyConsts<P> make_lazy() {
     return c;
 }
 template <class P> struct Lazy { static constexpr LazyConsts<P> L = make_lazy<P>(); };
+
+// k * p in normalised limbs for every k = 0 .. 32 (only the rows a kernel names become literals in its code): lets a subtraction
+// add exactly the multiple its subtrahend needs (6p for PPP + 2Q) instead of the next power of two, which keeps the bounds of the
+// curve formulas where they were when several subtrahends share one pass.
+template <class P>
+struct MultConsts { uint32_t mp[33][P::NL]; };
+template <class P>
+constexpr MultConsts<P> make_multiples() {
+    MultConsts<P> c{};
+    for (int k = 1; k <= 32; k++) {
+        uint32_t carry = 0;
+        for (int i = 0; i < P::NL; i++) { uint32_t x = c.mp[k - 1][i] + P::C.mod[i] + carry; carry = x >> LB; c.mp[k][i] = x & LMASK; }
+    }
+    return c;
+}
+template <class P> struct Mult { static constexpr MultConsts<P> M = make_multiples<P>(); };
 static_assert(Bls381Fp::NL * LB - Bls381Fp::BITS >= 7 && Bls381Fr::NL * LB - Bls381Fr::BITS >= 7 && Bn254Fp::NL * LB - Bn254Fp::BITS >= 7,
               "p / R < 2^-7 is assumed by the lazy multiplication bound");
 
@@ -406,39 +520,8 @@ template <int B2, class P, int B1> BP_HD FeB<P, B2> feb_widen(const FeB<P, B1>& 
 
 template <class P, int B1, int B2> BP_HD FeB<P, 2> feb_mul(const FeB<P, B1>& a, const FeB<P, B2>& b) {
     static_assert(B1 * B2 <= kMaxProd, "operands too large for a lazy Montgomery product");
-    constexpr int N = P::NL;
-    uint32_t t[2 * N];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N - 1; k++) {
-#pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; BP_KEEP_ORDER(acc); }
-        t[k] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
-    t[2 * N - 1] = (uint32_t)acc;
-    uint32_t m[N];
-    uint32_t one = 1;
-    BP_OPAQUE_ONE(one);
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
-#pragma unroll
-        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
-        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
-        { acc += (uint64_t)m[k] * P::C.mod[0]; BP_KEEP_ORDER(acc); }
-        acc >>= LB;
-    }
     FeB<P, 2> r;
-#pragma unroll
-    for (int k = N; k < 2 * N; k++) {
-        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
-#pragma unroll
-        for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
-        r.v[k - N] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
+    mont_core<P, false, false, true>(a.v, b.v, nullptr, r.v);
     return r;
 }
 
@@ -448,7 +531,7 @@ template <class P, int B1, int B2, int B3, int B4>
 BP_HD FeB<P, 2> feb_mul_add_mul(const FeB<P, B1>& a1, const FeB<P, B2>& b1, const FeB<P, B3>& a2, const FeB<P, B4>& b2) {
     static_assert(B1 * B2 + B3 * B4 <= kMaxProd, "operands too large for a shared lazy reduction");
     constexpr int N = P::NL;
-    uint32_t t[2 * N];
+    uint32_t t[2 * N];                      // a1 b1 as 2N normalised limbs; the fused core adds them to a2 b2 column by column
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; k++) {
@@ -458,37 +541,8 @@ BP_HD FeB<P, 2> feb_mul_add_mul(const FeB<P, B1>& a1, const FeB<P, B2>& b1, cons
         acc >>= LB;
     }
     t[2 * N - 1] = (uint32_t)acc;
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N - 1; k++) {
-#pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) { acc += (uint64_t)a2.v[i] * b2.v[k - i]; BP_KEEP_ORDER(acc); }
-        t[k] += (uint32_t)acc & LMASK;           // < 2^31: the reduction below adds t[k] into a 64-bit column
-        acc >>= LB;
-    }
-    t[2 * N - 1] += (uint32_t)acc;
-    uint32_t m[N];
-    uint32_t one = 1;
-    BP_OPAQUE_ONE(one);
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
-#pragma unroll
-        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
-        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
-        { acc += (uint64_t)m[k] * P::C.mod[0]; BP_KEEP_ORDER(acc); }
-        acc >>= LB;
-    }
     FeB<P, 2> r;
-#pragma unroll
-    for (int k = N; k < 2 * N; k++) {
-        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
-#pragma unroll
-        for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
-        r.v[k - N] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
+    mont_core<P, false, true, true>(a2.v, b2.v, t, r.v);
     return r;
 }
 
@@ -509,43 +563,8 @@ template <int K, class P, int B> BP_HD FeB<P, K> feb_neg(const FeB<P, B>& a) {
 
 template <class P, int B1> BP_HD FeB<P, 2> feb_sqr(const FeB<P, B1>& a) {
     static_assert(B1 * B1 <= kMaxProd, "operand too large for a lazy Montgomery square");
-    constexpr int N = P::NL;
-    uint32_t a2[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) a2[i] = a.v[i] << 1;
-    uint32_t t[2 * N];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * N - 1; k++) {
-#pragma unroll
-        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; BP_KEEP_ORDER(acc); }
-        if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; BP_KEEP_ORDER(acc); }
-        t[k] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
-    t[2 * N - 1] = (uint32_t)acc;
-    uint32_t m[N];
-    uint32_t one = 1;
-    BP_OPAQUE_ONE(one);
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
-#pragma unroll
-        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
-        m[k] = ((uint32_t)acc * P::C.inv) & LMASK;
-        { acc += (uint64_t)m[k] * P::C.mod[0]; BP_KEEP_ORDER(acc); }
-        acc >>= LB;
-    }
     FeB<P, 2> r;
-#pragma unroll
-    for (int k = N; k < 2 * N; k++) {
-        { acc += (uint64_t)t[k] * one; BP_KEEP_ORDER(acc); }
-#pragma unroll
-        for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::C.mod[k - i]; BP_KEEP_ORDER(acc); }
-        r.v[k - N] = (uint32_t)acc & LMASK;
-        acc >>= LB;
-    }
+    mont_core<P, true, false, true>(a.v, a.v, nullptr, r.v);
     return r;
 }
 
@@ -572,6 +591,48 @@ template <int K, class P, int B1, int B2> BP_HD FeB<P, B1 + K> feb_sub(const FeB
         int32_t x = (int32_t)(a.v[i] + Lazy<P>::L.kp[ki][i]) - (int32_t)b.v[i] + c;   // in (-2^30, 2^31 + 2)
         r.v[i] = (uint32_t)x & LMASK;
         c = x >> LB;                                                                   // arithmetic shift: signed carry
+    }
+    return r;
+}
+
+// a - b + K p for ANY K in [B2, 32] (feb_sub above takes powers of two only)
+template <int K, class P, int B1, int B2> BP_HD FeB<P, B1 + K> feb_subk(const FeB<P, B1>& a, const FeB<P, B2>& b) {
+    static_assert(K >= B2 && K <= 32 && B1 + K <= 32, "K p must dominate the subtrahend");
+    FeB<P, B1 + K> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        int32_t x = (int32_t)(a.v[i] + Mult<P>::M.mp[K][i]) - (int32_t)b.v[i] + c;
+        r.v[i] = (uint32_t)x & LMASK;
+        c = x >> LB;
+    }
+    return r;
+}
+
+// a - b - c + K p in ONE carry pass, K >= B2 + B3 (every limb sum stays inside a signed 32-bit word: a + Kp < 2^31, b + c < 2^31)
+template <int K, class P, int B1, int B2, int B3> BP_HD FeB<P, B1 + K> feb_sub2k(const FeB<P, B1>& a, const FeB<P, B2>& b, const FeB<P, B3>& c3) {
+    static_assert(K >= B2 + B3 && K <= 32 && B1 + K <= 32, "K p must dominate both subtrahends");
+    FeB<P, B1 + K> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        int32_t x = (int32_t)(a.v[i] + Mult<P>::M.mp[K][i]) - (int32_t)b.v[i] - (int32_t)c3.v[i] + c;
+        r.v[i] = (uint32_t)x & LMASK;
+        c = x >> LB;
+    }
+    return r;
+}
+
+// p - a for a CANONICAL a (0 <= a <= p - 1; a = 0 gives p, which is 0 mod p and inside the bound): the negation of an affine
+// coordinate without the add-back pass of the strict fe_neg
+template <class P> BP_HD FeB<P, 2> feb_neg_canonical(const Fe<P>& a) {
+    FeB<P, 2> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) {
+        int32_t x = (int32_t)P::C.mod[i] - (int32_t)a.v[i] + c;
+        r.v[i] = (uint32_t)x & LMASK;
+        c = x >> LB;
     }
     return r;
 }

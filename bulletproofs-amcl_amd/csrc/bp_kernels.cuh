@@ -396,13 +396,29 @@ __global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* 
     if (j >= *total_tasks) return;
     uint32_t tid = order[j];
     uint32_t s = t_start[tid], e = s + t_len[tid];
-    // lazy-reduction accumulator (bounded domain, bp_curve.cuh): no conditional subtraction inside the loop
+    using Fp = typename C::Fp;
+    // lazy-reduction accumulator (bounded domain, bp_curve.cuh): no conditional subtraction inside the loop.
+    // Two nested loops: the outer one takes ONE point through the general addition (empty accumulator, identity point, doubling,
+    // cancellation), the inner one is the single-path addition and runs until the task ends or a point needs the general form.
+    // With uniformly random input the outer body runs once per task (its first point).
     XyzzLazy<C> acc = xyzz_lazy_inf<C>();
-    for (; s < e; s++) {
-        uint32_t code = idx[s];
-        Aff<C> p = aff_unpack(pts[code & 0x7fffffffu]);
-        if (code >> 31) p.y = fe_neg(p.y);
-        xyzz_lazy_add_aff(acc, p);
+    while (s < e) {
+        {
+            uint32_t code = idx[s++];
+            Aff<C> p = aff_unpack(pts[code & 0x7fffffffu]);
+            if (code >> 31) p.y = fe_neg(p.y);
+            xyzz_lazy_add_aff(acc, p);
+        }
+        if (acc.inf) continue;
+        while (s < e) {
+            const uint32_t code = idx[s];
+            const Aff<C> p = aff_unpack(pts[code & 0x7fffffffu]);
+            if (aff_is_inf(p)) { s++; continue; }
+            FeB<Fp, 2> qy = feb_widen<2>(feb_from_strict<Fp>(p.y));
+            if (code >> 31) qy = feb_neg_canonical<Fp>(p.y);
+            if (!xyzz_lazy_add_aff_fast(acc, feb_from_strict<Fp>(p.x), qy)) break;     // same x: the outer loop handles this point
+            s++;
+        }
     }
     tsum[tid] = xyzz_lazy_pack(acc);     // bounded, not canonical: every consumer works in the same lazy domain
 }
