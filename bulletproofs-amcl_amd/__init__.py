@@ -18,6 +18,7 @@ _SO = os.environ.get("BPMSM_SO") or os.path.join(_HERE, "libbpmsm.so")   # overr
 BP_OK, BP_ERR_LENGTH, BP_ERR_ARG, BP_ERR_VERIFY, BP_ERR_DEVICE = 0, 1, 2, 3, 4
 BLS12_381, BN254 = 0, 1
 FMT_LE, FMT_AMCL = 0, 1
+TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM = 1, 2, 3, 4   # bp_ctx_set_tuning knobs (include/bpmsm.h)
 CURVE_IDS = {"bls12_381": BLS12_381, "bn254": BN254}
 
 
@@ -69,12 +70,16 @@ SYMBOLS = {
     "bp_ctx_set_stream": (_I, [_P, _P]),
     "bp_ctx_synchronize": (_I, [_P]),
     "bp_ctx_set_window_bits": (_I, [_P, _I]),
+    "bp_ctx_set_tuning": (_I, [_P, _I, ctypes.c_long]),
     "bp_ctx_set_device_tail": (_I, [_P, _I]),
     "bp_ctx_enable_timing": (_I, [_P, _I]),
     "bp_g1vec_upload": (_I, [_P, _U8P, _SZ, _I, _PP]),
     "bp_g1vec_alloc": (_I, [_P, _SZ, _PP]),
     "bp_g1vec_download": (_I, [_P, _P, _SZ, _SZ, _I, _U8P]),
     "bp_g1vec_free": (_I, [_P]),
+    "bp_g1vec_precompute": (_I, [_P, _P, _I]),
+    "bp_g1vec_drop_table": (_I, [_P]),
+    "bp_g1vec_table_info": (_I, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t)]),
     "bp_g1vec_len": (_SZ, [_P]),
     "bp_g1vec_device_ptr": (_P, [_P]),
     "bp_g1vec_wrap_device": (_I, [_P, _P, _SZ, _PP]),
@@ -216,6 +221,7 @@ class Context:
         self.fp_bytes, self.fr_bytes, self.modbytes = info.fp_bytes, info.fr_bytes, info.modbytes
         self.point_bytes = 2 * info.fp_bytes
         self.r = int.from_bytes(bytes(info.r_le), "little")
+        self.fr_bits = info.fr_bits
 
     def close(self):
         if self.h:
@@ -243,6 +249,10 @@ class Context:
 
     def set_window_bits(self, c):
         _check(lib().bp_ctx_set_window_bits(self.h, c), "bp_ctx_set_window_bits")
+
+    def set_tuning(self, knob, value):
+        """validated engineering knobs of the MSM pipeline (TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM); 0 = automatic"""
+        _check(lib().bp_ctx_set_tuning(self.h, knob, value), "bp_ctx_set_tuning")
 
     def set_ipp_fold_generators(self, on):
         _check(lib().bp_ctx_set_ipp_fold_generators(self.h, 1 if on else 0), "bp_ctx_set_ipp_fold_generators")
@@ -362,6 +372,21 @@ class G1Vector:
         _check(lib().bp_msm_g1_pair(self.ctx.h, self.h, scalars1.h, scalars2.h, o1, o2), "bp_msm_g1_pair")
         return o1.raw, o2.raw
 
+    def precompute(self, window_bits=0):
+        """build the window-multiples table of this (fixed) vector: every later MSM over the whole vector runs the merged-window
+        pipeline (bp_g1vec_precompute); same bytes with and without"""
+        _check(lib().bp_g1vec_precompute(self.ctx.h, self.h, window_bits), "bp_g1vec_precompute")
+        return self
+
+    def drop_table(self):
+        _check(lib().bp_g1vec_drop_table(self.h), "bp_g1vec_drop_table")
+
+    def table_info(self):
+        """-> (window_bits, windows, bytes); zeros without a table"""
+        c, w, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        _check(lib().bp_g1vec_table_info(self.h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(b)), "bp_g1vec_table_info")
+        return c.value, w.value, b.value
+
     def msm_range(self, poff, scalars, soff, n):
         out = ctypes.create_string_buffer(self.ctx.point_bytes)
         _check(lib().bp_msm_g1_range(self.ctx.h, self.h, poff, scalars.h, soff, n, out), "bp_msm_g1_range")
@@ -475,7 +500,7 @@ def msm_geometry(curve, n, window_bits=0):
 def msm_record_positions(curve, n, window_bits=0):
     """-> [pos_r]: record r of a block carries weight 2^pos_r (bp_msm_record_positions)"""
     k = ctypes.c_int()
-    pos = (ctypes.c_uint16 * 1024)()
+    pos = (ctypes.c_uint16 * 4096)()
     _check(lib().bp_msm_record_positions(curve, n, window_bits, ctypes.byref(k), ctypes.cast(pos, ctypes.c_void_p)), "bp_msm_record_positions")
     return list(pos[:k.value])
 

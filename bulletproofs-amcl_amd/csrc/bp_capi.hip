@@ -9,19 +9,65 @@
 using namespace bp;
 
 // ------------------------------------------------------------------------------------------------ geometry
-constexpr int kMaxGroups = 8;
 struct MsmGeom {
     int c;           // target window width
     WinTab tab;      // W windows of nearly equal width covering fr_bits + 1 bits
-    uint32_t m;      // buckets per reduce thread (windows outside the last group)
-    int ngroups;     // window groups processed as a software pipeline on two streams
-    int gw[kMaxGroups + 1];   // group k = windows [gw[k], gw[k+1])
-    // tail records handed to the host: kRecPerWin per window; record r carries weight 2^rpos[r] (bp_host_tail.hpp folds any such list)
+    uint32_t m;      // buckets per reduce thread (a power of two; windows with fewer buckets use their bucket count)
+    bool small;      // n <= kSmallMsmMax: the single-launch path, one record per window
+    bool merged;     // MSM over a window-multiples table: tab describes the digit windows, tabv the merged buckets (one "window" per scalar set)
+    WinTab tabv;     // merged only: the view the kernels after the coarse scatter run with (k_fine_place .. k_window_sums)
+    // tail records handed to the host: record r carries weight 2^rpos[r] (bp_host_tail.hpp folds any such list)
     int nrec;
-    uint16_t rpos[kRecPerWin * kMaxWindows];
+    uint16_t rpos[kMaxRecords];
 };
 
-static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0) {
+static int ilog2(uint32_t v) { int l = 0; while ((1u << (l + 1)) <= v) l++; return l; }
+
+// Reduce geometry on the table the reduce kernels run with (t = g.tab, or g.tabv in merged mode): buckets per reduce thread, the
+// compact block grid, and the tail records with their bit positions.
+static int geom_reduce(MsmGeom& g, WinTab& t, const bp_tuning* tn) {
+    const int W = t.W;
+    // Buckets per reduce thread: the smallest power of two whose blocks fit one per CU.  A 257th block makes some SIMD run two of
+    // these dependent chains back to back (measured: c = 14 paired, 304 blocks 1.26 ms, 152 blocks 0.86 ms; scripts/time_pair.py).
+    auto blocks_for = [&](uint32_t m) {
+        uint32_t blocks = 0;
+        for (int w = 0; w < W; w++) {
+            uint32_t B = t.boff[w + 1] - t.boff[w], mw = m < B ? m : B;
+            blocks += (B / mw + kBlock - 1) / kBlock;
+        }
+        return blocks;
+    };
+    uint32_t m = 1;
+    while (m < (1u << 15) && blocks_for(m) > 256) m <<= 1;
+    if (tn && tn->reduce_m) m = tn->reduce_m;
+    g.m = m;
+    uint32_t rb = 0, nrec = 0;
+    for (int w = 0; w < W; w++) {
+        const uint32_t B = t.boff[w + 1] - t.boff[w], mw = m < B ? m : B;
+        const uint32_t T = B / mw, nblk = (T + kBlock - 1) / kBlock;
+        t.lgm[w] = (uint8_t)ilog2(mw);
+        t.rboff[w] = (uint16_t)rb;
+        rb += nblk;
+        t.roff[w] = (uint16_t)nrec;
+        if (g.small) {                                         // one record per window: the window sum itself
+            if (nrec < (uint32_t)kMaxRecords) g.rpos[nrec] = t.off[w];
+            nrec += 1;
+        } else {                                               // tri, then one plane per bit of the reduce-thread index
+            const int planes = ilog2(T);
+            for (int k = 0; k <= planes; k++)
+                if (nrec + k < (uint32_t)kMaxRecords) g.rpos[nrec + k] = (uint16_t)(k == 0 ? t.off[w] : t.off[w] + t.lgm[w] + (k - 1));
+            nrec += 1 + planes;
+        }
+    }
+    t.rboff[W] = (uint16_t)rb;
+    t.roff[W] = (uint16_t)nrec;
+    g.nrec = (int)nrec;
+    if (nrec > (uint32_t)kMaxRecords || rb > 65535u) return BP_ERR_ARG;
+    return BP_OK;
+}
+
+// tn: the context's validated tuning knobs (nullptr: defaults)
+static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0, const bp_tuning* tn = nullptr) {
     int c = c_override;
     if (c <= 0) {
         int lg = 0;
@@ -39,9 +85,14 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
             c--;
         }
     }
+    const bool small_ok = !tn || tn->small_msm;
+    // The single-launch path emits one record per window, the bucket pipeline 1 + log2(reduce threads): callers that must agree on
+    // a record layout across shards fix the window width (bp_ctx_set_window_bits / bp_msm_g1_multi), and a fixed width always means
+    // the pipeline's layout -- a 5-point shard beside a 2^20-point one then folds with it.
+    g.small = n <= kSmallMsmMax && small_ok && c_override <= 0;
     // k_small_msm (n <= kSmallMsmMax): each lane multiplies by its digit, so narrow windows shorten the chain; below c = 4 the
     // extra windows cost more on the host (one addition per window in the tail) than they save on the device
-    if (c_override <= 0 && n <= kSmallMsmMax && c > 4) c = 4;
+    if (c_override <= 0 && g.small && c > 4) c = 4;
     if (c < 2) c = 2;
     if (c > 16) c = 16;
     g.c = c;
@@ -88,47 +139,59 @@ static void msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nset
     t.hoff[W] = (uint16_t)rows;
     t.nbuckets = nb;
     memcpy(t.bias.w, bias, sizeof bias);
-    // Window groups (msm_windows; opt-in with BP_GROUPS=k, default 1): the W windows processed as k contiguous groups, the tail of
-    // one group (bucket reduce: ~2m + 30 dependent point operations at one wave per SIMD) and the memory-bound sort of the next
-    // running beside the ALU-bound accumulate of another.  Built and measured in round 2 as VERDICT r1 #3 asked -- it LOSES:
-    // 4.44 ms (1 group) -> 4.94 (2) -> 5.69 (4) -> 9.6 ms (8) at n = 2^20.  A group's accumulate has only W/k * 2^15 tasks for the
-    // 131072 resident lanes, so the longest-first balancing has nothing to balance with (4 windows: one task per lane, the kernel
-    // lasts as long as the longest of 131072 Poisson(32) buckets, ~1.6x the mean), and the reduce chain of the last, exposed group
-    // is as long as the chain for all windows (its length is set by log2 of the buckets per window, not by their number).
-    static const int g_env = getenv("BP_GROUPS") ? atoi(getenv("BP_GROUPS")) : 0;
-    int G = 1;                      // measured (profiles/r02_window_groups.txt): more groups are SLOWER on this part, see below
-    if (g_env > 0) G = g_env;
-    if (G > W) G = W;
-    if (G > kMaxGroups) G = kMaxGroups;
-    g.ngroups = G;
-    for (int k = 0; k <= G; k++) g.gw[k] = (int)((long)W * k / G);
-    // Buckets per reduce thread, per group: the smallest m whose ACTIVE blocks fit one per CU -- all windows together for the
-    // groups whose reduce is hidden (work-efficient: few long chains), the last group alone for the one that is exposed (shorter
-    // chain).  A 257th block makes some SIMD run two such chains back to back (measured: c = 14 paired, 304 blocks 1.26 ms,
-    // 152 blocks 0.86 ms; scripts/time_pair.py).
-    static const uint32_t m_env = getenv("BP_REDUCE_M") ? (uint32_t)atoi(getenv("BP_REDUCE_M")) : 0;
-    auto pick_m = [&](int w0, int w1) {
-        uint32_t m = 1;
-        for (; m < 16; m++) {
-            uint32_t blocks = 0;
-            for (int w = w0; w < w1; w++) { uint32_t B = t.boff[w + 1] - t.boff[w]; blocks += ((B + m - 1) / m + kBlock - 1) / kBlock; }
-            if (blocks <= 256) break;
-        }
-        return m_env ? m_env : m;
-    };
-    const uint32_t m_all = pick_m(0, W), m_last = G > 1 ? pick_m(g.gw[G - 1], W) : m_all;
-    g.m = m_all;
-    uint32_t rb = 0;
+    // (Round 2 also carried an opt-in pipeline of window groups on several streams here.  It was measured slower at every group
+    // count -- 4.44 -> 4.94 / 5.69 / 9.6 ms for 2 / 4 / 8 groups at n = 2^20, profiles/r02_window_groups.txt -- and was removed in
+    // round 3; DESIGN.md section 5 keeps the analysis.)
+    g.merged = false;
+    return geom_reduce(g, t, tn);
+}
+
+// Geometry of an MSM over a window-multiples table (bp_g1vec_precompute) with window width c: W1 windows per scalar set at bit
+// offsets c w (the last one narrower), all of a set's windows sharing its 2^(c-1) buckets.
+static int msm_geom_table(MsmGeom& g, int fr_bits, int c, int W1, int nsets, const bp_tuning* tn) {
+    const int cover = fr_bits + 1;
+    if (c < 2 || c > 16 || W1 != (cover + c - 1) / c || W1 * nsets > kMaxWindows) return BP_ERR_ARG;
+    g.c = c;
+    g.small = false;
+    g.merged = true;
+    WinTab& t = g.tab;
+    memset(&t, 0, sizeof t);
+    const int W = W1 * nsets;
+    const int fb = c - 1 < 8 ? c - 1 : 8;
+    const uint32_t B = 1u << (c - 1), bins = 1u << (c - 1 - fb);
+    t.W = W; t.nsets = nsets; t.merged = 1; t.W1 = (uint16_t)W1;
+    uint32_t bias[8] = {0};
     for (int w = 0; w < W; w++) {
-        const uint32_t m = w >= g.gw[G - 1] ? m_last : m_all;
-        t.mw[w] = (uint8_t)m;
-        t.rboff[w] = (uint16_t)rb;
-        uint32_t B = t.boff[w + 1] - t.boff[w];
-        rb += ((B + m - 1) / m + kBlock - 1) / kBlock;
+        const int w1 = w % W1, set = w / W1, off = c * w1;
+        const int cw = cover - off < c ? cover - off : c;
+        t.cw[w] = (uint8_t)cw;
+        t.off[w] = (uint16_t)off;
+        t.boff[w] = (uint32_t)set * B;
+        t.fbits[w] = (uint8_t)fb;
+        t.hoff[w] = (uint16_t)(set * bins);
+        if (set) continue;
+        unsigned __int128 add = (unsigned __int128)(((uint64_t)1 << (cw - 1)) - 1) << (off & 31);
+        uint64_t carry = 0;
+        for (int k = off >> 5; k < 8; k++) {
+            uint64_t v = (uint64_t)bias[k] + (uint64_t)(add & 0xffffffffu) + carry;
+            bias[k] = (uint32_t)v;
+            carry = v >> 32;
+            add >>= 32;
+            if (!add && !carry) break;
+        }
     }
-    t.rboff[W] = (uint16_t)rb;
-    for (int w = 0; w < W; w++) g.rpos[w] = t.off[w];
-    g.nrec = kRecPerWin * W;
+    t.boff[W] = (uint32_t)nsets * B;
+    t.hoff[W] = (uint16_t)(nsets * bins);
+    t.nbuckets = (uint32_t)nsets * B;
+    memcpy(t.bias.w, bias, sizeof bias);
+    // the view: one window of c bits per scalar set
+    WinTab& v = g.tabv;
+    memset(&v, 0, sizeof v);
+    v.W = nsets; v.nsets = nsets; v.W1 = 1;
+    for (int s2 = 0; s2 <= nsets; s2++) { v.boff[s2] = (uint32_t)s2 * B; v.hoff[s2] = (uint16_t)(s2 * bins); }
+    for (int s2 = 0; s2 < nsets; s2++) { v.cw[s2] = (uint8_t)c; v.off[s2] = 0; v.fbits[s2] = (uint8_t)fb; }
+    v.nbuckets = t.nbuckets;
+    return geom_reduce(g, v, tn);
 }
 
 // ------------------------------------------------------------------------------------------------ per-curve code
@@ -141,118 +204,110 @@ struct Impl {
     static int ensure_events(bp_ctx* ctx) {
         if (ctx->ev_ready) return BP_OK;
         for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
-        for (auto& e : ctx->ev_acc) HIPCHK(hipEventCreate(&e));
-        for (auto& e : ctx->ev_sync) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : ctx->ev_tail) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->ev_ready = true;
         return BP_OK;
     }
 
-    // Device stage: window sums of  sum_i s_i P_i  into ctx->window_sum (W records).
+    // Device stage: tail records of  sum_i s_i P_i  into ctx->window_sum (g.nrec records).
+    // host_rec: records in the host's form (the fold of bp_host_tail.hpp); false: lazy XYZZ for the device-side tail (k_tail_fold)
     static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g, const ScalarWords* sc2 = nullptr,
-                           size_t nnz = 0) {
-        msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz);
-        const WinTab& tab = g.tab;
-        const int W = tab.W;
-        if (getenv("BP_TRACE")) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d nbuckets=%u m=%u reduce_blocks=%u\n", n, g.c, W, tab.nbuckets, g.m, (unsigned)tab.rboff[W]);
+                           size_t nnz = 0, bool host_rec = true, const bp_g1table* tb = nullptr) {
+        // tb: window-multiples table of `pts` (same n): the merged-window pipeline over its rows
+        int rc = tb ? msm_geom_table(g, C::Fr::BITS, tb->c, tb->W, sc2 ? 2 : 1, &ctx->tuning)
+                    : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning);
+        if (rc) return rc;
+        if (tb) { if (tb->n != n || (uint64_t)tb->W * n >= ((uint64_t)1 << 31)) return BP_ERR_ARG; pts = (const AffPacked<C>*)tb->d; }
+        const WinTab& tab = g.tab;                          // digit windows: k_digits_bin, k_coarse_scatter
+        const WinTab& tabR = g.merged ? g.tabv : g.tab;     // buckets as the later kernels see them
+        const int W = tab.W, WR = tabR.W;
+        if (bp_trace_on()) fprintf(stderr, "[bpmsm trace] msm n=%zu c=%d W=%d merged=%d nbuckets=%u m=%u reduce_blocks=%u records=%d\n", n, g.c, W, (int)g.merged, tab.nbuckets, g.m, (unsigned)tabR.rboff[WR], g.nrec);
         if (n >= ((size_t)1 << 31)) return BP_ERR_ARG;                      // the sign lives in bit 31 of an index
         if ((uint64_t)W * n >= ((uint64_t)1 << 32)) return BP_ERR_ARG;      // 32-bit slot offsets
         hipStream_t st = ctx->stream;
-        static const bool small_path = getenv("BP_SMALL_MSM") ? atoi(getenv("BP_SMALL_MSM")) != 0 : true;
-        if (n <= kSmallMsmMax && small_path) {   // one launch: block per window, lane per term (k_small_msm)
-            int rc0;
-            if ((rc0 = ctx->window_sum.reserve((size_t)g.nrec * kXyzzBytes))) return rc0;
-            const bool tm0 = ctx->timing;
-            ctx->last_groups = 0;
-            if (tm0) { if ((rc0 = ensure_events(ctx))) return rc0; for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st)); }
-            hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
+        const bool tm = ctx->timing;
+        if (tm && (rc = ensure_events(ctx))) return rc;
+        if ((rc = ctx->window_sum.reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
+        if (g.small) {   // one launch: block per window, lane per term (k_small_msm)
+            if (tm) for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st));
+            if (!host_rec) hipLaunchKernelGGL((k_small_msm<C, false>), dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
+            else hipLaunchKernelGGL((k_small_msm<C, true>), dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
-            if (tm0) HIPCHK(hipEventRecord(ctx->ev[6], st));
+            if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
             HIPCHK(hipGetLastError());
             return BP_OK;
         }
         const size_t nb = tab.nbuckets;
-        const int G = g.ngroups;
         // task length (see bp_kernels.cuh): >= 2x the mean bucket size when buckets are plentiful, else small enough
-        // for ~kTaskTarget tasks (a few times the 131072 resident lanes of k_accumulate)
-        static const uint64_t kTaskTarget = getenv("BP_TASK_TARGET") ? (uint64_t)atoll(getenv("BP_TASK_TARGET")) : 2 * 131072;
+        // for ~task_target tasks (a few times the 131072 resident lanes of k_accumulate)
+        const uint64_t kTaskTarget = ctx->tuning.task_target ? ctx->tuning.task_target : 2 * 131072;
         const uint64_t entries = (uint64_t)W * (nnz ? nnz : n);
         uint32_t L = 8;
         if (nb >= kTaskTarget) { while ((uint64_t)L * nb < 2 * entries && L < (1u << 20)) L <<= 1; if (L < 128) L = 128; }
         else { while ((uint64_t)L * kTaskTarget < entries && L < (1u << 20)) L <<= 1; }
         uint32_t lshift = 0;
         while ((128u << lshift) < L) lshift++;
-        // per-group capacities (group k owns buckets [boff[gw[k]], boff[gw[k+1]]) and its own task / heavy lists)
-        struct Grp { int w0, w1; size_t b0, nb, max_tasks, max_heavy, max_chunks, scan_blocks, task_base, heavy_base, chunk_base, bsum_base; };
-        Grp gr[kMaxGroups];
-        size_t tot_tasks = 0, tot_heavy = 0, tot_chunks = 0, tot_bsum = 0;
-        for (int k = 0; k < G; k++) {
-            Grp& q = gr[k];
-            q.w0 = g.gw[k]; q.w1 = g.gw[k + 1];
-            q.b0 = tab.boff[q.w0]; q.nb = tab.boff[q.w1] - q.b0;
-            const size_t slots = (size_t)(q.w1 - q.w0) * n;
-            size_t max_split = slots / L + 1;                                 // tasks beyond one per bucket
-            if (max_split > slots) max_split = slots;
-            q.max_tasks = q.nb + max_split;
-            q.max_heavy = (q.nb < max_split ? q.nb : max_split) + 1;
-            q.max_chunks = q.max_heavy + q.max_tasks / kBlock + 1;
-            q.scan_blocks = (q.nb + kScanPerBlock - 1) / kScanPerBlock;
-            q.task_base = tot_tasks; q.heavy_base = tot_heavy; q.chunk_base = tot_chunks; q.bsum_base = tot_bsum;
-            tot_tasks += q.max_tasks; tot_heavy += q.max_heavy; tot_chunks += q.max_chunks; tot_bsum += q.scan_blocks + 16;
-        }
-        int rc;
-        if ((rc = ctx->count.reserve(nb * 4))) return rc;
-        if ((rc = ctx->cursor.reserve(nb * 4))) return rc;
-        if ((rc = ctx->ntasks.reserve(nb * 4))) return rc;
-        if ((rc = ctx->task_off.reserve(nb * 4))) return rc;
-        if ((rc = ctx->idx.reserve((size_t)W * n * 4))) return rc;
-        if ((rc = ctx->code.reserve((size_t)W * n * 2))) return rc;
-        if ((rc = ctx->order.reserve(tot_tasks * 4))) return rc;
-        if ((rc = ctx->t_start.reserve(tot_tasks * 4))) return rc;
-        if ((rc = ctx->t_len.reserve(tot_tasks * 4))) return rc;
-        if ((rc = ctx->tsum.reserve(tot_tasks * kXyzzBytes))) return rc;
-        if ((rc = ctx->heavy.reserve(tot_heavy * 4))) return rc;
-        if ((rc = ctx->heavy_chunks.reserve(tot_chunks * sizeof(uint2)))) return rc;
-        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16;      // per group, 64-byte aligned
-        if ((rc = ctx->meta.reserve(kMaxGroups * kMetaWords * 4))) return rc;
-        if ((rc = ctx->partial.reserve((size_t)tab.rboff[W] * kXyzzBytes))) return rc;
-        if ((rc = ctx->window_sum.reserve((size_t)g.nrec * kXyzzBytes))) return rc;
+        const size_t slots = (size_t)W * n;
+        size_t max_split = slots / L + 1;                                 // tasks beyond one per bucket
+        if (max_split > slots) max_split = slots;
+        const size_t max_tasks = nb + max_split;
+        const size_t max_heavy = (nb < max_split ? nb : max_split) + 1;
+        const size_t max_chunks = max_heavy + max_tasks / kBlock + 1;
+        const size_t scan_blocks = (nb + kScanPerBlock - 1) / kScanPerBlock;
+        if ((rc = ctx->count.reserve(ctx, nb * 4))) return rc;
+        if ((rc = ctx->cursor.reserve(ctx, nb * 4))) return rc;
+        if ((rc = ctx->ntasks.reserve(ctx, nb * 4))) return rc;
+        if ((rc = ctx->task_off.reserve(ctx, nb * 4))) return rc;
+        if ((rc = ctx->idx.reserve(ctx, (size_t)W * n * 4))) return rc;
+        if ((rc = ctx->code.reserve(ctx, (size_t)W * n * 2))) return rc;
+        if ((rc = ctx->order.reserve(ctx, max_tasks * 4))) return rc;
+        if ((rc = ctx->t_start.reserve(ctx, max_tasks * 4))) return rc;
+        if ((rc = ctx->t_len.reserve(ctx, max_tasks * 4))) return rc;
+        if ((rc = ctx->tsum.reserve(ctx, max_tasks * kXyzzBytes))) return rc;
+        if ((rc = ctx->heavy.reserve(ctx, max_heavy * 4))) return rc;
+        if ((rc = ctx->heavy_chunks.reserve(ctx, max_chunks * sizeof(uint2)))) return rc;
+        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16;
+        if ((rc = ctx->meta.reserve(ctx, kMetaWords * 4))) return rc;
+        if ((rc = ctx->partial.reserve(ctx, (size_t)tabR.rboff[WR] * kPartPerBlock * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // bucket starts
         uint32_t* cursor = (uint32_t*)ctx->cursor.p;     // bucket ends
         uint32_t* ntasks = (uint32_t*)ctx->ntasks.p;
-        uint32_t* task_off = (uint32_t*)ctx->task_off.p; // task ids are local to the bucket's group
+        uint32_t* task_off = (uint32_t*)ctx->task_off.p;
         uint32_t* idx = (uint32_t*)ctx->idx.p;
         uint16_t* code = (uint16_t*)ctx->code.p;
         auto* partial = (XyzzPacked<C>*)ctx->partial.p;
         auto* wsum = (XyzzPacked<C>*)ctx->window_sum.p;
 
-        // Tile = scalars per block of the binning passes (BP_TILE: 2048 .. 16384 measured within 1 % of each other at 2^18 .. 2^22).
-        static const uint32_t tile_env = getenv("BP_TILE") ? (uint32_t)atoi(getenv("BP_TILE")) : 0;
+        // Tile = scalars per block of the binning passes (2048 .. 16384 measured within 1 % of each other at 2^18 .. 2^22).
         // Below ~2^19 scalars a 2048-scalar tile leaves the per-scalar passes with a few dozen blocks for 256 CUs (n = 2^17: 65 blocks,
         // k_digits_bin 71 us); the tile shrinks (never below one scalar per lane) until there are ~512 of them.
         uint32_t tile = kTile;
         while (tile > (uint32_t)kBlock && (n + tile - 1) / tile < 512) tile >>= 1;
-        if (tile_env) tile = tile_env;
+        if (ctx->tuning.tile) tile = ctx->tuning.tile;              // validated by bp_ctx_set_tuning: a multiple of kBlock
         const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
+        const uint32_t ncols = g.merged ? ntiles * (uint32_t)tab.W1 : ntiles;     // columns of the tile histogram: (window of the set, tile) when merged
         const uint32_t rows = tab.hoff[W];
-        const size_t nhist = (size_t)rows * ntiles;
+        const size_t nhist = (size_t)rows * ncols;
         const size_t hist_blocks = (nhist + kScanPerBlock - 1) / kScanPerBlock;
-        if ((rc = ctx->tile_hist.reserve(nhist * 4))) return rc;
-        if ((rc = ctx->tmp_idx.reserve((size_t)W * n * 8))) return rc;            // (point index, digit code) records of the coarse pass
-        if ((rc = ctx->block_sums.reserve((hist_blocks + 16 + tot_bsum) * 4))) return rc;
+        if ((rc = ctx->tile_hist.reserve(ctx, nhist * 4))) return rc;
+        if ((rc = ctx->tmp_idx.reserve(ctx, (size_t)W * n * 8))) return rc;            // (point index, digit code) records of the coarse pass
+        if ((rc = ctx->block_sums.reserve(ctx, (hist_blocks + 16 + scan_blocks + 16) * 4))) return rc;
         uint32_t* hsum = (uint32_t*)ctx->block_sums.p;                 // scan of the tile histogram; hsum[hist_blocks] = grand total
-        uint32_t* gsum = hsum + hist_blocks + 16;                      // per-group task scans
+        uint32_t* bsum = hsum + hist_blocks + 16;                      // scan of the task counts
         uint32_t* tile_hist = (uint32_t*)ctx->tile_hist.p;
         uint2* tmp_rec = (uint2*)ctx->tmp_idx.p;
+        uint32_t* bins = (uint32_t*)ctx->meta.p;                       // [kTaskBins] bin counts -> bin cursors
+        uint32_t* total_tasks = bins + kTaskBins;
+        uint32_t* nheavy = bins + kTaskBins + 1;
+        uint32_t* nchunks = bins + kTaskBins + 2;
+        uint32_t* order = (uint32_t*)ctx->order.p;
+        uint32_t* t_start = (uint32_t*)ctx->t_start.p;
+        uint32_t* t_len = (uint32_t*)ctx->t_len.p;
+        auto* tsum = (XyzzPacked<C>*)ctx->tsum.p;
+        uint32_t* heavy = (uint32_t*)ctx->heavy.p;
+        uint2* chunks = (uint2*)ctx->heavy_chunks.p;
 
-        const bool tm = ctx->timing;
-        if ((rc = ensure_events(ctx))) return rc;
-        if (G > 1) {
-            if (!ctx->aux_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-            for (int k = 0; k < G; k++) if (!ctx->tail_stream[k]) HIPCHK(hipStreamCreateWithFlags(&ctx->tail_stream[k], hipStreamNonBlocking));
-        }
         if (tm) HIPCHK(hipEventRecord(ctx->ev[0], st));
-        HIPCHK(hipMemsetAsync(ctx->meta.p, 0, (size_t)G * kMetaWords * 4, st));
+        HIPCHK(hipMemsetAsync(ctx->meta.p, 0, kMetaWords * 4, st));
         hipLaunchKernelGGL(k_digits_bin, dim3(ntiles), dim3(kBlock), 0, st, sc, sc2, n, tab, ntiles, tile, code, tile_hist);
         BP_TRACE_SYNC(ctx, "k_digits_bin");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
@@ -260,80 +315,39 @@ struct Impl {
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, hsum, tile_hist, (uint32_t*)nullptr);
         BP_TRACE_SYNC(ctx, "scan tile_hist");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
-        if (G > 1) {   // fork: the auxiliary stream continues from here
-            HIPCHK(hipEventRecord(ctx->ev_sync[0], st));
-            HIPCHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_sync[0], 0));
-        }
-        static const int wps = getenv("BP_ACC_WPS") ? atoi(getenv("BP_ACC_WPS")) : 2;
-        // Schedule: group k sorts on front stream k & 1 and accumulates there as soon as group k - 1 has finished accumulating
-        // (the accumulates run back to back, they are what bounds the MSM); its tail -- combine, bucket reduce, window sums:
-        // ~2m + 30 dependent point operations at one wave per SIMD -- goes to a stream of its own and runs beside the next
-        // groups' accumulates, as does the memory-bound sort of the next group.  Only the last group's tail is exposed.
-        for (int k = 0; k < G; k++) {
-            const Grp& q = gr[k];
-            hipStream_t sk = (k & 1) ? ctx->aux_stream : st;
-            const int Wg = q.w1 - q.w0;
-            uint32_t* bins = (uint32_t*)ctx->meta.p + (size_t)k * kMetaWords;      // [kTaskBins] bin counts -> bin cursors
-            uint32_t* total_tasks = bins + kTaskBins;
-            uint32_t* nheavy = bins + kTaskBins + 1;
-            uint32_t* nchunks = bins + kTaskBins + 2;
-            uint32_t* order = (uint32_t*)ctx->order.p + q.task_base;
-            uint32_t* t_start = (uint32_t*)ctx->t_start.p + q.task_base;
-            uint32_t* t_len = (uint32_t*)ctx->t_len.p + q.task_base;
-            auto* tsum = (XyzzPacked<C>*)ctx->tsum.p + q.task_base;
-            uint32_t* heavy = (uint32_t*)ctx->heavy.p + q.heavy_base;
-            uint2* chunks = (uint2*)ctx->heavy_chunks.p + q.chunk_base;
-            uint32_t* bsum = gsum + q.bsum_base;
-            hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, Wg), dim3(kBlock), 0, sk, code, n, tab, ntiles, tile_hist, tmp_rec, q.w0, tile);
-            BP_TRACE_SYNC(ctx, "k_coarse_scatter");
-            hipLaunchKernelGGL(k_fine_place, dim3(128, Wg), dim3(kBlock), 0, sk, tmp_rec, tab, ntiles, tile_hist, hsum + hist_blocks, count, cursor, idx, q.w0);
-            BP_TRACE_SYNC(ctx, "k_fine_place");
-            if (tm && k == 0) HIPCHK(hipEventRecord(ctx->ev[3], sk));
-            // count[] = bucket starts, cursor[] = bucket ends.  Tasks of this group (bucket ids local to the group from here on):
-            const unsigned bgrid = (unsigned)((q.nb + kBlock * kTaskPer - 1) / (kBlock * kTaskPer));   // kTaskPer buckets per lane
-            hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, sk, count + q.b0, cursor + q.b0, (uint32_t)q.nb, L, lshift, ntasks + q.b0, bins);
-            hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, sk, bins, total_tasks);
-            hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)q.scan_blocks), dim3(kBlock), 0, sk, ntasks + q.b0, q.nb, bsum);
-            hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)q.scan_blocks), dim3(kBlock), 0, sk, ntasks + q.b0, q.nb, bsum, task_off + q.b0, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, sk, count + q.b0, cursor + q.b0, (uint32_t)q.nb, L, lshift, task_off + q.b0, bins, order, t_start, t_len,
-                               heavy, nheavy, chunks, nchunks);
-            BP_TRACE_SYNC(ctx, "k_task_emit");
-            if (tm && k == 0) HIPCHK(hipEventRecord(ctx->ev[4], sk));
-            if (k > 0) HIPCHK(hipStreamWaitEvent(sk, ctx->ev_acc[2 * (k - 1) + 1], 0));
-            if (tm) HIPCHK(hipEventRecord(ctx->ev_acc[2 * k], sk));
-            {
-                dim3 agrid((unsigned)((q.max_tasks + kBlock - 1) / kBlock));
-                if (wps == 2) hipLaunchKernelGGL((k_accumulate<C, 2>), agrid, dim3(kBlock), 0, sk, pts, idx, order, t_start, t_len, total_tasks, tsum);
-                else if (wps == 4) hipLaunchKernelGGL((k_accumulate<C, 4>), agrid, dim3(kBlock), 0, sk, pts, idx, order, t_start, t_len, total_tasks, tsum);
-                else hipLaunchKernelGGL((k_accumulate<C, 3>), agrid, dim3(kBlock), 0, sk, pts, idx, order, t_start, t_len, total_tasks, tsum);
-            }
-            if (G > 1 || tm) HIPCHK(hipEventRecord(ctx->ev_acc[2 * k + 1], sk));
-            if (tm && k == G - 1) HIPCHK(hipEventRecord(ctx->ev[5], sk));
-            hipStream_t tk = sk;
-            if (G > 1) { tk = ctx->tail_stream[k]; HIPCHK(hipStreamWaitEvent(tk, ctx->ev_acc[2 * k + 1], 0)); }
-            hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(q.max_chunks < 256 ? q.max_chunks : 256)), dim3(kBlock), 0, tk, chunks, nchunks, task_off + q.b0, ntasks + q.b0, tsum);
-            hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)(q.max_heavy < 256 ? q.max_heavy : 256)), dim3(kBlock), 0, tk, heavy, nheavy, task_off + q.b0, ntasks + q.b0, tsum);
-            BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
-            hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tab.rboff[q.w1] - tab.rboff[q.w0]), dim3(kBlock), 0, tk, tsum, task_off, ntasks, tab, (uint32_t)tab.rboff[q.w0], partial);
-            BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
-            hipLaunchKernelGGL(k_window_sums<C>, dim3(Wg), dim3(kBlock), 0, tk, partial, tab, wsum, q.w0);
-            BP_TRACE_SYNC(ctx, "k_window_sums<C>");
-            if (G > 1) HIPCHK(hipEventRecord(ctx->ev_tail[k], tk));
-        }
-        if (G > 1) {   // join: everything the caller queues on the context's stream next sees all groups (and both front streams)
-            HIPCHK(hipEventRecord(ctx->ev_sync[1], ctx->aux_stream));
-            HIPCHK(hipStreamWaitEvent(st, ctx->ev_sync[1], 0));
-            for (int k = 0; k < G; k++) HIPCHK(hipStreamWaitEvent(st, ctx->ev_tail[k], 0));
-        }
+        hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, W), dim3(kBlock), 0, st, code, n, tab, ntiles, tile_hist, tmp_rec, 0, tile);
+        BP_TRACE_SYNC(ctx, "k_coarse_scatter");
+        hipLaunchKernelGGL(k_fine_place, dim3(128, WR), dim3(kBlock), 0, st, tmp_rec, tabR, ncols, tile_hist, hsum + hist_blocks, count, cursor, idx, 0);
+        BP_TRACE_SYNC(ctx, "k_fine_place");
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[3], st));
+        // count[] = bucket starts, cursor[] = bucket ends
+        const unsigned bgrid = (unsigned)((nb + kBlock * kTaskPer - 1) / (kBlock * kTaskPer));   // kTaskPer buckets per lane
+        hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, ntasks, bins);
+        hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, st, bins, total_tasks);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum, task_off, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len,
+                           heavy, nheavy, chunks, nchunks);
+        BP_TRACE_SYNC(ctx, "k_task_emit");
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));
+        hipLaunchKernelGGL((k_accumulate<C, 2>), dim3((unsigned)((max_tasks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pts, idx, order, t_start, t_len, total_tasks, tsum);
+        BP_TRACE_SYNC(ctx, "k_accumulate<C>");
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[5], st));
+        hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(max_chunks < 256 ? max_chunks : 256)), dim3(kBlock), 0, st, chunks, nchunks, task_off, ntasks, tsum);
+        hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)(max_heavy < 256 ? max_heavy : 256)), dim3(kBlock), 0, st, heavy, nheavy, task_off, ntasks, tsum);
+        BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tabR.rboff[WR]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tabR, partial);
+        BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
+        if (!host_rec) hipLaunchKernelGGL((k_window_sums<C, false>), dim3(WR, kPartPerBlock), dim3(kBlock), 0, st, partial, tabR, wsum);
+        else hipLaunchKernelGGL((k_window_sums<C, true>), dim3(WR, kPartPerBlock), dim3(kBlock), 0, st, partial, tabR, wsum);
+        BP_TRACE_SYNC(ctx, "k_window_sums<C>");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
-        ctx->last_groups = G;
         HIPCHK(hipGetLastError());
         return BP_OK;
     }
 
-    // last_ms: [0] whole device pipeline, [1] digits + histograms, [2] scan, [3] scatter and [4] task lists of the first window
-    // group, [5] accumulate = SUM over the window groups' launches (each measured on its own stream; with more than one group
-    // other kernels run beside them), [6] end of the last accumulate -> end of the pipeline (the exposed tail)
+    // last_ms: [0] whole device pipeline, [1] digits + histograms, [2] scan, [3] scatter, [4] task lists, [5] accumulate,
+    // [6] end of the accumulate -> end of the pipeline (combine, bucket reduce, window sums)
     static void collect_timing(bp_ctx* ctx) {
         ctx->last_ms_n = 0;
         if (!ctx->timing || !ctx->ev_ready) return;
@@ -342,16 +356,33 @@ struct Impl {
         if (hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[6]) == hipSuccess) ctx->last_ms[0] = t;
         for (int i = 0; i < 6; i++)
             if (hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]) == hipSuccess) ctx->last_ms[1 + i] = t;
-        if (ctx->last_groups > 0) {
-            float acc = 0;
-            for (int k = 0; k < ctx->last_groups; k++)
-                if (hipEventElapsedTime(&t, ctx->ev_acc[2 * k], ctx->ev_acc[2 * k + 1]) == hipSuccess) acc += t;
-            ctx->last_ms[5] = acc;
-        }
         ctx->last_ms_n = 7;
     }
 
     static const host::Tail<C>& tail() { static const host::Tail<C> t; return t; }
+
+    // nfolds independent folds (1, or the 2 of a paired MSM), each dealt to `chains` Horner walks that run on the context's helper
+    // threads beside the calling thread (bp_host_tail.hpp).  Few records: one chain per fold (the walk is then 255 doublings and a
+    // handful of additions; threads would only add their wake-up latency).
+    static void fold_parallel(bp_ctx* ctx, int nfolds, const XyzzPacked<C>* const* rec, size_t sets, int nrec, const uint16_t* const* pos, uint8_t* const* out_le) {
+        using Jac = typename host::Tail<C>::Jac;
+        const host::Tail<C>& tl = tail();
+        int chains = ctx && ctx->tail_chains > 0 ? ctx->tail_chains : ((size_t)nrec * sets >= 48 ? 4 : 1);
+        if (chains > host::Tail<C>::kMaxChains) chains = host::Tail<C>::kMaxChains;
+        if (!ctx) chains = 1;
+        Jac parts[2 * host::Tail<C>::kMaxChains];
+        const int njobs = nfolds * chains;
+        std::function<void(int)> job = [&](int j) { tl.fold_chain(rec[j / chains], sets, nrec, pos[j / chains], j % chains, chains, &parts[j]); };
+        if (njobs == 1) job(0);
+        else ctx->tail_pool.run(njobs, job, njobs - 1);
+        if (nfolds == 2) {
+            std::function<void(int)> fin = [&](int f) { tl.finish(parts + f * chains, chains, out_le[f]); };
+            ctx->tail_pool.run(2, fin, 1);
+        } else tl.finish(parts, chains, out_le[0]);
+    }
+    static void fold1(bp_ctx* ctx, const XyzzPacked<C>* rec, size_t sets, int nrec, const uint16_t* pos, uint8_t* out_le) {
+        fold_parallel(ctx, 1, &rec, sets, nrec, &pos, &out_le);
+    }
 
     static void aff_to_le(const Aff<C>& a, uint8_t* out) {
         uint32_t w[Fp::NW];
@@ -361,18 +392,21 @@ struct Impl {
         memcpy(out + 4 * Fp::NW, w, 4 * Fp::NW);
     }
 
-    static int msm(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, uint8_t* out_le) {
+    static int msm(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, uint8_t* out_le, const bp_g1table* tb = nullptr) {
         if (n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); ctx->last_ms_n = 0; return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g, nullptr, 0, !ctx->device_tail, tb);
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
-        if (ctx->device_tail) {   // all-device variant: one lane folds the windows (see k_tail_fold)
-            if ((rc = ctx->scratch.reserve(2 * 4 * Fp::NW))) return rc;
-            hipLaunchKernelGGL(k_tail_fold<C>, dim3(1), dim3(64), 0, ctx->stream, (const XyzzPacked<C>*)ctx->window_sum.p, g.tab, 0, g.tab.W,
-                               (uint32_t*)ctx->scratch.p);
+        if (ctx->device_tail) {   // all-device variant: one lane folds the records (see k_tail_fold)
+            const size_t pos_bytes = ((size_t)g.nrec * 2 + 15) & ~(size_t)15;
+            if ((rc = ctx->scratch.reserve(ctx, pos_bytes + 2 * 4 * Fp::NW))) return rc;
+            memcpy(ctx->host_pinned, g.rpos, (size_t)g.nrec * 2);          // host_pinned holds at least nrec records: room for nrec positions
+            HIPCHK(hipMemcpyAsync(ctx->scratch.p, ctx->host_pinned, (size_t)g.nrec * 2, hipMemcpyHostToDevice, ctx->stream));
+            uint32_t* dev_out = (uint32_t*)((uint8_t*)ctx->scratch.p + pos_bytes);
+            hipLaunchKernelGGL(k_tail_fold<C>, dim3(1), dim3(64), 0, ctx->stream, (const XyzzPacked<C>*)ctx->window_sum.p, (const uint16_t*)ctx->scratch.p, g.nrec, dev_out);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(out_le, ctx->scratch.p, 2 * 4 * Fp::NW, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(out_le, dev_out, 2 * 4 * Fp::NW, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             collect_timing(ctx);
             return BP_OK;
@@ -380,18 +414,18 @@ struct Impl {
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, g.nrec, g.rpos, out_le);
+        fold1(ctx, (const XyzzPacked<C>*)ctx->host_pinned, 1, g.nrec, g.rpos, out_le);
         return BP_OK;
     }
 
     // Asynchronous form of msm(): begin() queues the device pipeline and the D2H copy of the window sums on the
     // context's stream and returns; end() waits for them and runs the host tail.  One MSM in flight per context.
-    static int msm_begin(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n) {
+    static int msm_begin(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, const bp_g1table* tb = nullptr) {
         ctx->pending = false;
         ctx->pending_n = n;
         if (n == 0) { ctx->pending = true; return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g, nullptr, 0, true, tb);
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -406,43 +440,42 @@ struct Impl {
         if (ctx->pending_n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        tail().fold((const XyzzPacked<C>*)ctx->host_pinned, 1, ctx->pending_nrec, ctx->pending_rpos, out_le);
+        fold1(ctx, (const XyzzPacked<C>*)ctx->host_pinned, 1, ctx->pending_nrec, ctx->pending_rpos, out_le);
         return BP_OK;
     }
 
     // Two scalar sets over the same points in ONE pipeline pass (2W windows): out1 = <sc1, pts>, out2 = <sc2, pts>.
-    static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le, size_t nnz = 0) {
+    static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le, size_t nnz = 0, const bp_g1table* tb = nullptr) {
         if (n == 0) { memset(out1_le, 0, 2 * 4 * Fp::NW); memset(out2_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz, true, tb);
         if (rc) return rc;
         const int R1 = g.nrec / 2;                      // records of one scalar set
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        // the two serial tails (~0.12 ms each: 255 dependent doublings) are independent: fold the second on the context's helper thread
-        const host::Tail<C>& tl = tail();
+        // the two tails are independent: their Horner chains run side by side on the context's helper threads
         const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
-        const bool helped = ctx->worker.submit([&]() { tl.fold(rec + R1, 1, R1, g.rpos + R1, out2_le); });
-        tl.fold(rec, 1, R1, g.rpos, out1_le);
-        if (helped) ctx->worker.wait();
-        else tl.fold(rec + R1, 1, R1, g.rpos + R1, out2_le);   // no thread available: fold both here
+        const XyzzPacked<C>* recs[2] = {rec, rec + R1};
+        const uint16_t* poss[2] = {g.rpos, g.rpos + R1};
+        uint8_t* outs[2] = {out1_le, out2_le};
+        fold_parallel(ctx, 2, recs, 1, R1, poss, outs);
         return BP_OK;
     }
 
     // Record block of the two-stage (sharded) form: W window records followed by ONE header record that names the geometry
     // which produced them, so that bp_msm_g1_finish can refuse sets that do not fit together (ranks whose shard sizes straddle
     // a power of two pick different window widths unless the caller fixes c with bp_ctx_set_window_bits).
-    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, rec_per_win; };   // widths: n_wide windows of cw_first bits, then cw_last
+    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, nrec, m, small; };   // widths: n_wide windows of cw_first bits, then cw_last
     static_assert(sizeof(RecHeader) <= sizeof(XyzzPacked<C>), "header must fit one record");
-    static constexpr uint32_t kRecMagic = 0x31575042u;   // "BPW1"
+    static constexpr uint32_t kRecMagic = 0x32575042u;   // "BPW2" (round 3: bit-plane records; a round-2 block "BPW1" is refused)
     static void fill_header(RecHeader& h, const MsmGeom& g) {
         memset(&h, 0, sizeof h);
         h.magic = kRecMagic; h.c = (uint32_t)g.c; h.W = (uint32_t)g.tab.W; h.fr_bits = (uint32_t)C::Fr::BITS;
         h.cw_first = g.tab.cw[0]; h.cw_last = g.tab.cw[g.tab.W - 1];
         for (int w = 0; w < g.tab.W; w++) if (g.tab.cw[w] == g.tab.cw[0]) h.n_wide++;
-        h.rec_per_win = kRecPerWin;
+        h.nrec = (uint32_t)g.nrec; h.m = g.m; h.small = g.small ? 1u : 0u;
     }
 
     static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
@@ -462,30 +495,34 @@ struct Impl {
     }
 
     // host_rec: sets x (W + 1) records in host memory (header last in each set); validates the headers and folds
-    static int finish_host(int c_override, const XyzzPacked<C>* host_rec, size_t sets, size_t n_per_set, uint8_t* out_le) {
+    static int finish_host(int c_override, const XyzzPacked<C>* host_rec, size_t sets, size_t n_per_set, uint8_t* out_le, const bp_tuning* tn = nullptr, bp_ctx* ctx = nullptr) {
         MsmGeom g;
-        msm_geom(g, C::Fr::BITS, n_per_set, c_override);
+        if (msm_geom(g, C::Fr::BITS, n_per_set, c_override, 1, 0, tn)) return BP_ERR_ARG;
         const int W = g.nrec;
         RecHeader want;
         fill_header(want, g);
-        std::vector<XyzzPacked<C>> packed(sets * (size_t)W);
+        std::vector<XyzzPacked<C>> packed;
+        try { packed.resize(sets * (size_t)W); } catch (...) { return BP_ERR_DEVICE; }     // no exception crosses the C ABI
         for (size_t s = 0; s < sets; s++) {
             const XyzzPacked<C>* set = host_rec + s * (size_t)(W + 1);
             if (memcmp(&set[W], &want, sizeof want) != 0) return BP_ERR_ARG;     // geometry of this set differs from the caller's
             memcpy(&packed[s * (size_t)W], set, (size_t)W * kXyzzBytes);
         }
-        tail().fold(packed.data(), sets, W, g.rpos, out_le);
+        fold1(ctx, packed.data(), sets, W, g.rpos, out_le);
         return BP_OK;
     }
 
     // bp_msm_g1_multi, device half of one shard: queue the pipeline with the shared window width c and the D2H copy of the W
     // window sums into this context's pinned buffer; no synchronisation.
-    static int multi_begin(bp_ctx* ctx, const bp_g1vec* pts, const bp_frvec* sc, int c, int* W_out) {
+    static int multi_begin(bp_ctx* ctx, const bp_g1vec* pts, const bp_frvec* sc, int c, const bp_tuning* tn, int* W_out) {
         const int saved = ctx->c_override;
+        const bp_tuning saved_tn = ctx->tuning;
         ctx->c_override = c;
+        ctx->tuning = *tn;                       // one geometry for every shard: the first context's knobs
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts->d, (const ScalarWords*)sc->d, pts->n, g);
         ctx->c_override = saved;
+        ctx->tuning = saved_tn;
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -493,35 +530,32 @@ struct Impl {
         return BP_OK;
     }
 
-    // one affine point (canonical LE) -> a packed XYZZ record in the device's Montgomery radix (host arithmetic)
+    // one affine point (canonical LE) -> a tail record in the host's form (bp_host_tail.hpp)
     static void record_from_affine(const uint8_t* le, XyzzPacked<C>* out) {
         uint32_t xw[Fp::NW], yw[Fp::NW];
         memcpy(xw, le, 4 * Fp::NW);
         memcpy(yw, le + 4 * Fp::NW, 4 * Fp::NW);
-        Aff<C> a;
-        a.x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
-        a.y = fe_to_mont<Fp>(fe_unpack_words<Fp>(yw));
-        *out = xyzz_pack(xyzz_from_aff(a));
+        tail().record_from_affine(xw, yw, out);
     }
 
     static int msm_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
         MsmGeom g;
-        msm_geom(g, C::Fr::BITS, n_per_set, ctx->c_override);
+        if (msm_geom(g, C::Fr::BITS, n_per_set, ctx->c_override, 1, 0, &ctx->tuning)) return BP_ERR_ARG;
         size_t bytes = sets * (size_t)(g.nrec + 1) * kXyzzBytes;
         int rc;
         if ((rc = host_pinned_reserve(ctx, bytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, device_records, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
-        return finish_host(ctx->c_override, (const XyzzPacked<C>*)ctx->host_pinned, sets, n_per_set, out_le);
+        return finish_host(ctx->c_override, (const XyzzPacked<C>*)ctx->host_pinned, sets, n_per_set, out_le, &ctx->tuning, ctx);
     }
 
     // validate = true: BP_ERR_ARG if a coordinate is >= p or a point is off the curve (see k_points_to_resident)
     static int upload_points(bp_ctx* ctx, const uint8_t* le, size_t n, void* d_out, bool validate) {
         size_t bytes = n * 2 * 4 * Fp::NW;
         int rc;
-        if ((rc = ctx->scratch.reserve(bytes ? bytes : 16))) return rc;
-        if ((rc = ctx->flags.reserve(64))) return rc;
+        if ((rc = ctx->scratch.reserve(ctx, bytes ? bytes : 16))) return rc;
+        if ((rc = ctx->flags.reserve(ctx, 64))) return rc;
         uint32_t* flag = validate ? (uint32_t*)ctx->flags.p : nullptr;
         uint32_t host_flag = 0;
         if (flag) HIPCHK(hipMemsetAsync(flag, 0, 4, ctx->stream));
@@ -536,7 +570,7 @@ struct Impl {
 
     static int check_scalars(bp_ctx* ctx, const void* d_sc, size_t n) {
         int rc;
-        if ((rc = ctx->flags.reserve(64))) return rc;
+        if ((rc = ctx->flags.reserve(ctx, 64))) return rc;
         uint32_t* flag = (uint32_t*)ctx->flags.p;
         uint32_t host_flag = 0;
         HIPCHK(hipMemsetAsync(flag, 0, 4, ctx->stream));
@@ -550,7 +584,7 @@ struct Impl {
     static int download_points(bp_ctx* ctx, const void* d_in, size_t offset, size_t n, uint8_t* le) {
         size_t bytes = n * 2 * 4 * Fp::NW;
         int rc;
-        if ((rc = ctx->scratch.reserve(bytes ? bytes : 16))) return rc;
+        if ((rc = ctx->scratch.reserve(ctx, bytes ? bytes : 16))) return rc;
         hipLaunchKernelGGL(k_points_from_resident<C>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
                            (const AffPacked<C>*)d_in + offset, n, (uint32_t*)ctx->scratch.p);
         HIPCHK(hipGetLastError());
@@ -564,8 +598,8 @@ struct Impl {
         if (ctx->fixed_base_ready) return BP_OK;
         const size_t m = (size_t)kFixedBaseWindows * 15;
         int rc;
-        if ((rc = ctx->fixed_base_table.reserve(m * kPointBytes))) return rc;
-        if ((rc = ctx->scratch.reserve(m * 32))) return rc;
+        if ((rc = ctx->fixed_base_table.reserve(ctx, m * kPointBytes))) return rc;
+        if ((rc = ctx->scratch.reserve(ctx, m * 32))) return rc;
         std::vector<ScalarWords> ks(m);
         for (int j = 0; j < kFixedBaseWindows; j++)
             for (int d = 1; d <= 15; d++) {
@@ -612,13 +646,39 @@ static int set_device(const bp_ctx* ctx) {
 }
 int bp_internal_set_device(const bp_ctx* ctx) { return set_device(ctx); }
 
-int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le) {
-    DISPATCH(ctx, I::msm(ctx, points, 0, scalars, 0, n, out_le));
+int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le, const bp_g1table* tb) {
+    DISPATCH(ctx, I::msm(ctx, points, 0, scalars, 0, n, out_le, tb));
 }
 
 int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
-                     size_t nnz) {
-    DISPATCH(ctx, I::msm2(ctx, points, scalars1, scalars2, n, out1_le, out2_le, nnz));
+                     size_t nnz, const bp_g1table* tb) {
+    DISPATCH(ctx, I::msm2(ctx, points, scalars1, scalars2, n, out1_le, out2_le, nnz, tb));
+}
+
+// Window-multiples table of n resident points (bp_g1vec_precompute): allocated from the context's pool, built on its stream.
+int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp_g1table** out) {
+    *out = nullptr;
+    const int fr_bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
+    if (c < 2 || c > 16 || n == 0) return BP_ERR_ARG;
+    const int W1 = (fr_bits + 1 + c - 1) / c;
+    if ((uint64_t)W1 * n >= ((uint64_t)1 << 31)) return BP_ERR_ARG;           // a table row index shares its word with the sign bit
+    const size_t pt = 2 * (size_t)fp_bytes_of(ctx->curve), xz = bp_msm_record_bytes(ctx->curve);
+    bp_g1table* t = new (std::nothrow) bp_g1table();
+    if (!t) return BP_ERR_DEVICE;
+    t->pool = ctx->pool; t->device = ctx->device; t->n = n; t->c = c; t->W = W1;
+    t->d = ctx->pool->get((size_t)W1 * n * pt, &t->cap);
+    PoolBlock tmp, pre;                                                        // parked XYZZ values and running products (returned to the pool in stream order)
+    if (!t->d || !tmp.alloc(ctx, (size_t)(W1 - 1) * n * xz + 16) || !pre.alloc(ctx, (size_t)(W1 - 1) * n * (pt / 2) + 16)) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_table_build<Bls381>, grid, dim3(kBlock), 0, ctx->stream, (const AffPacked<Bls381>*)points, n, c, W1, (XyzzPacked<Bls381>*)tmp.p,
+                           (FePacked<Bls381Fp>*)pre.p, (AffPacked<Bls381>*)t->d);
+    else
+        hipLaunchKernelGGL(k_table_build<Bn254>, grid, dim3(kBlock), 0, ctx->stream, (const AffPacked<Bn254>*)points, n, c, W1, (XyzzPacked<Bn254>*)tmp.p,
+                           (FePacked<Bn254Fp>*)pre.p, (AffPacked<Bn254>*)t->d);
+    if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    *out = t;
+    return BP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -678,16 +738,9 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     ctx->fixed_base_table.release();
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
                       &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags}) b->release();
-    if (ctx->pool) ctx->pool->release();     // cached blocks go back to the driver; live handles keep the pool itself alive
+    if (ctx->pool) { ctx->pool->trim(); ctx->pool->release(); }     // cached blocks go back to the driver now; live handles keep the (empty) pool alive
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
-    if (ctx->ev_ready) {
-        for (auto& e : ctx->ev) (void)hipEventDestroy(e);
-        for (auto& e : ctx->ev_acc) (void)hipEventDestroy(e);
-        for (auto& e : ctx->ev_sync) (void)hipEventDestroy(e);
-        for (auto& e : ctx->ev_tail) (void)hipEventDestroy(e);
-    }
-    for (auto& t : ctx->tail_stream) if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
-    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->ev_ready) for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return BP_OK;
@@ -706,6 +759,7 @@ bp_ctx* bp_internal_helper(bp_ctx* ctx, int k) {
     bp_ctx* h = ctx->helper[k];
     h->c_override = ctx->c_override;
     h->device_tail = ctx->device_tail;
+    h->tuning = ctx->tuning;
     return h;
 }
 int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling) {
@@ -737,6 +791,30 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c) {
     if (!ctx || c < 0 || c > 16 || c == 1) return BP_ERR_ARG;
     ctx->c_override = c;
     return BP_OK;
+}
+
+int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
+    if (!ctx || value < 0) return BP_ERR_ARG;
+    switch (knob) {
+    case BP_TUNE_TILE:          // k_digits_bin / k_coarse_scatter give every lane tile / 256 scalars: anything else would skip scalars
+        if (value != 0 && (value < kBlock || value > 16384 || value % kBlock)) return BP_ERR_ARG;
+        ctx->tuning.tile = (uint32_t)value;
+        return BP_OK;
+    case BP_TUNE_REDUCE_M:      // the bit-plane records need a power of two
+        if (value != 0 && (value > 16384 || (value & (value - 1)))) return BP_ERR_ARG;
+        ctx->tuning.reduce_m = (uint32_t)value;
+        return BP_OK;
+    case BP_TUNE_TASK_TARGET:
+        if (value != 0 && (value < 1024 || value > (1L << 28))) return BP_ERR_ARG;
+        ctx->tuning.task_target = (uint64_t)value;
+        return BP_OK;
+    case BP_TUNE_SMALL_MSM:
+        if (value > 1) return BP_ERR_ARG;
+        ctx->tuning.small_msm = value != 0;
+        return BP_OK;
+    default:
+        return BP_ERR_ARG;
+    }
 }
 
 int bp_ctx_set_device_tail(bp_ctx* ctx, int on) {
@@ -827,15 +905,64 @@ int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, i
     return BP_OK;
 }
 
+void bp_internal_table_free(bp_g1table* t) {
+    if (!t) return;
+    if (t->d) t->pool->put(t->d, t->cap);
+    delete t;
+}
+
+// An owned block whose raw pointer was handed out (bp_*_device_ptr: torch / RCCL streams, views on other contexts) may still be
+// read by streams this library does not know: wait for the device, as the hipFree of the pre-pool code did, before the block can
+// be handed out again.  Everything else is ordered on the owner's stream and goes back without synchronisation.
+static void recycle_block(DevPool* pool, int device, void* d, size_t cap, bool exported) {
+    if (exported) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (hipSetDevice(device) == hipSuccess) (void)hipDeviceSynchronize();
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    }
+    pool->put(d, cap);
+}
+
 int bp_g1vec_free(bp_g1vec* v) {
     if (!v) return BP_OK;
-    if (v->owned && v->d) v->pool->put(v->d, v->cap);     // back to the context's pool (no device synchronisation)
+    if (v->table) bp_internal_table_free(v->table);
+    if (v->owned && v->d) recycle_block(v->pool, v->device, v->d, v->cap, v->exported);
     delete v;
     return BP_OK;
 }
 
+int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits) {
+    if (!ctx || !v || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    if (v->n == 0) return BP_ERR_ARG;
+    int rc = set_device(ctx); if (rc) return rc;
+    int c = window_bits;
+    if (c == 0) {                                   // as the plain pipeline picks it, but never below 8 (a table row per 8 bits at most)
+        int lg = 0;
+        while (((size_t)1 << (lg + 1)) <= v->n) lg++;
+        c = lg - 1 < 8 ? 8 : lg - 1 > 16 ? 16 : lg - 1;
+    }
+    if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
+    return bp_internal_table_build(ctx, v->d, v->n, c, &v->table);
+}
+
+int bp_g1vec_drop_table(bp_g1vec* v) {
+    if (!v) return BP_ERR_ARG;
+    if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
+    return BP_OK;
+}
+
+int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_t* bytes) {
+    if (!v) return BP_ERR_ARG;
+    const bp_g1table* t = v->table;
+    if (window_bits) *window_bits = t ? t->c : 0;
+    if (windows) *windows = t ? t->W : 0;
+    if (bytes) *bytes = t ? (size_t)t->W * t->n * 2 * (size_t)fp_bytes_of(v->ctx->curve) : 0;
+    return BP_OK;
+}
+
 size_t bp_g1vec_len(const bp_g1vec* v) { return v ? v->n : 0; }
-void* bp_g1vec_device_ptr(bp_g1vec* v) { return v ? v->d : nullptr; }
+void* bp_g1vec_device_ptr(bp_g1vec* v) { if (!v) return nullptr; v->exported = true; return v->d; }
 
 int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out) {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
@@ -909,13 +1036,13 @@ int bp_frvec_copy(bp_ctx* ctx, bp_frvec* dst, size_t dst_off, const bp_frvec* sr
 
 int bp_frvec_free(bp_frvec* v) {
     if (!v) return BP_OK;
-    if (v->owned && v->d) v->pool->put(v->d, v->cap);
+    if (v->owned && v->d) recycle_block(v->pool, v->device, v->d, v->cap, v->exported);
     delete v;
     return BP_OK;
 }
 
 size_t bp_frvec_len(const bp_frvec* v) { return v ? v->n : 0; }
-void* bp_frvec_device_ptr(bp_frvec* v) { return v ? v->d : nullptr; }
+void* bp_frvec_device_ptr(bp_frvec* v) { if (!v) return nullptr; v->exported = true; return v->d; }
 
 int bp_frvec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_frvec** out) {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
@@ -928,7 +1055,8 @@ int bp_msm_g1_range(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_f
     if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
     if (poff > points->n || n > points->n - poff || soff > scalars->n || n > scalars->n - soff) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
-    DISPATCH(ctx, I::msm(ctx, points->d, poff, scalars->d, soff, n, out_le));
+    const bp_g1table* tb = (points->table && poff == 0 && n == points->n && points->table->n == n) ? points->table : nullptr;
+    DISPATCH(ctx, I::msm(ctx, points->d, poff, scalars->d, soff, n, out_le, tb));
 }
 
 int bp_msm_g1(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars, uint8_t* out_le) {
@@ -941,7 +1069,8 @@ int bp_msm_g1_begin(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars
     if (!ctx || !points || !scalars) return BP_ERR_ARG;
     if (points->n != scalars->n) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
-    DISPATCH(ctx, I::msm_begin(ctx, points->d, 0, scalars->d, 0, points->n));
+    const bp_g1table* tb = points->table && points->table->n == points->n ? points->table : nullptr;
+    DISPATCH(ctx, I::msm_begin(ctx, points->d, 0, scalars->d, 0, points->n, tb));
 }
 
 int bp_msm_g1_end(bp_ctx* ctx, uint8_t* out_le) {
@@ -954,15 +1083,15 @@ int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1
     if (!ctx || !points || !scalars1 || !scalars2 || !out1_le || !out2_le) return BP_ERR_ARG;
     if (points->n != scalars1->n || points->n != scalars2->n) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
-    return bp_internal_msm2(ctx, points->d, scalars1->d, scalars2->d, points->n, out1_le, out2_le, 0);
+    return bp_internal_msm2(ctx, points->d, scalars1->d, scalars2->d, points->n, out1_le, out2_le, 0, points->table && points->table->n == points->n ? points->table : nullptr);
 }
 
 size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {
     if (!ctx) return 0;
     int bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
     MsmGeom g;
-    msm_geom(g, bits, n, ctx->c_override);
-    return (size_t)g.nrec + 1;   // kRecPerWin records per window + the geometry header (see RecHeader)
+    if (msm_geom(g, bits, n, ctx->c_override, 1, 0, &ctx->tuning)) return 0;
+    return (size_t)g.nrec + 1;   // tail records + the geometry header (see RecHeader)
 }
 
 size_t bp_msm_record_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? sizeof(XyzzPacked<Bls381>) : sizeof(XyzzPacked<Bn254>); }
@@ -989,7 +1118,7 @@ int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, s
 int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32) {
     if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     MsmGeom g;
-    msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits);
+    if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits)) return BP_ERR_ARG;
     if (c_out) *c_out = g.c;
     if (W_out) *W_out = g.tab.W;
     for (int w = 0; w < g.tab.W; w++) { if (cw_out) cw_out[w] = g.tab.cw[w]; if (off_out) off_out[w] = g.tab.off[w]; }
@@ -1000,7 +1129,7 @@ int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_
 int bp_msm_record_positions(int curve_id, size_t n, int window_bits, int* nrec_out, uint16_t* pos_out) {
     if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     MsmGeom g;
-    msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits);
+    if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits)) return BP_ERR_ARG;
     if (nrec_out) *nrec_out = g.nrec;
     if (pos_out) for (int r = 0; r < g.nrec; r++) pos_out[r] = g.rpos[r];
     return BP_OK;
@@ -1016,7 +1145,7 @@ int bp_msm_record_from_affine(int curve_id, const uint8_t* point_le, void* recor
 int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_out) {
     if (!curve_ok(curve_id) || !record_out || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     MsmGeom g;
-    msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits);
+    if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits)) return BP_ERR_ARG;
     memset(record_out, 0, bp_msm_record_bytes(curve_id));
     if (curve_id == BP_CURVE_BLS12_381) Impl<Bls381>::fill_header(*(Impl<Bls381>::RecHeader*)record_out, g);
     else Impl<Bn254>::fill_header(*(Impl<Bn254>::RecHeader*)record_out, g);
@@ -1040,8 +1169,12 @@ int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp
     const size_t pbytes = 2 * (size_t)fp_bytes_of(curve);
     if (n_max == 0) { memset(out_le, 0, pbytes); return BP_OK; }
     MsmGeom g;
-    msm_geom(g, curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n_max, ctxs[0]->c_override);
+    const int fr_bits = curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
+    if (msm_geom(g, fr_bits, n_max, ctxs[0]->c_override, 1, 0, &ctxs[0]->tuning)) return BP_ERR_ARG;
+    if (msm_geom(g, fr_bits, n_max, g.c, 1, 0, &ctxs[0]->tuning)) return BP_ERR_ARG;     // the shards run with this width FIXED: the record layout of a fixed width
     const int c = g.c, W = g.nrec;
+    const bp_tuning tn0 = ctxs[0]->tuning;
+    try {                                        // std::vector / std::function may throw: nothing crosses the C ABI
     std::vector<int> rcs(n_shards, BP_OK), Ws(n_shards, W);
     std::vector<char> queued(n_shards, 0), live(n_shards, 0);
     for (size_t i = 0; i < n_shards; i++) {
@@ -1050,8 +1183,8 @@ int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp
         auto job = [&, i]() {
             bp_ctx* cx = ctxs[i];
             int rc = set_device(cx);
-            if (!rc) rc = curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::multi_begin(cx, points[i], scalars[i], c, &Ws[i])
-                                                      : Impl<Bn254>::multi_begin(cx, points[i], scalars[i], c, &Ws[i]);
+            if (!rc) rc = curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::multi_begin(cx, points[i], scalars[i], c, &tn0, &Ws[i])
+                                                      : Impl<Bn254>::multi_begin(cx, points[i], scalars[i], c, &tn0, &Ws[i]);
             rcs[i] = rc;
         };
         if (n_shards > 1 && ctxs[i]->worker.submit(job)) queued[i] = 1;
@@ -1074,9 +1207,13 @@ int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp
         all.insert(all.end(), (const uint8_t*)ctxs[i]->host_pinned, (const uint8_t*)ctxs[i]->host_pinned + (size_t)W * rec);
         sets++;
     }
-    if (curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().fold((const XyzzPacked<Bls381>*)all.data(), sets, W, g.rpos, out_le);
-    else Impl<Bn254>::tail().fold((const XyzzPacked<Bn254>*)all.data(), sets, W, g.rpos, out_le);
+    if (curve == BP_CURVE_BLS12_381) Impl<Bls381>::fold1(ctxs[0], (const XyzzPacked<Bls381>*)all.data(), sets, W, g.rpos, out_le);
+    else Impl<Bn254>::fold1(ctxs[0], (const XyzzPacked<Bn254>*)all.data(), sets, W, g.rpos, out_le);
     return BP_OK;
+    } catch (...) {
+        for (size_t i = 0; i < n_shards; i++) if (ctxs[i]) { (void)set_device(ctxs[i]); (void)hipStreamSynchronize(ctxs[i]->stream); }
+        return BP_ERR_DEVICE;
+    }
 }
 
 int bp_ctx_trim(bp_ctx* ctx) {

@@ -85,7 +85,7 @@ int decompress_impl(bp_ctx* ctx, const uint8_t* in, size_t n, bp_g1vec* out) {
     PoolBlock stage;
     if (!stage.alloc(ctx, n * per)) return BP_ERR_DEVICE;
     int rc;
-    if ((rc = ctx->flags.reserve(64))) return rc;
+    if ((rc = ctx->flags.reserve(ctx, 64))) return rc;
     uint32_t* flag = (uint32_t*)ctx->flags.p;
     uint32_t host_flag = 0;
     HIPCHK(hipMemsetAsync(flag, 0, 4, ctx->stream));

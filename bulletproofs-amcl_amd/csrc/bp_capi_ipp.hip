@@ -272,7 +272,7 @@ struct Ipp {
             return BP_ERR_DEVICE;
         void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
         auto cleanup = [&]() {};
-        if ((rc = ctx->flags.reserve(64))) return rc;
+        if ((rc = ctx->flags.reserve(ctx, 64))) return rc;
         uint32_t* flag = (uint32_t*)ctx->flags.p;     // Q, L, R come from the proof: validated (on the curve, canonical)
         uint32_t host_flag = 0;
         // challenges (Montgomery form) for the per-element products
@@ -361,7 +361,7 @@ struct Ipp {
             return BP_ERR_DEVICE;
         void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
         auto cleanup = [&]() {};
-        { int rcf = ctx->flags.reserve(64); if (rcf) return rcf; }
+        { int rcf = ctx->flags.reserve(ctx, 64); if (rcf) return rcf; }
         uint32_t* flag = (uint32_t*)ctx->flags.p;
         uint32_t host_flag = 0;
         ScalarWords *d_ch = (ScalarWords*)chd, *d_chi = d_ch + nch, *d_wa = d_chi + nch, *d_wb = d_wa + m;
@@ -438,7 +438,7 @@ static int r1cs_verifier_scalars_impl(bp_ctx* ctx, Transcript& t, const uint8_t*
         fr_to_le<F>(fe_sqr(ch[j]), u_sq + 32 * j);
         fr_to_le<F>(fe_sqr(ch_inv[j]), u_inv_sq + 32 * j);
     }
-    if ((rc = ctx->scratch.reserve((2 * lg_n + 1) * 32))) return rc;
+    if ((rc = ctx->scratch.reserve(ctx, (2 * lg_n + 1) * 32))) return rc;
     HIPCHK(hipMemcpyAsync(ctx->scratch.p, hch.data(), (2 * lg_n + 1) * 32, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_r1cs_verifier_scalars<C>, dim3(blocks_for(padded_n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)wL->d,
                        (const ScalarWords*)wR->d, (const ScalarWords*)wO->d, (const ScalarWords*)ctx->scratch.p, (const ScalarWords*)ctx->scratch.p + lg_n,
@@ -599,7 +599,7 @@ int bp_fr_inner_product(bp_ctx* ctx, const bp_frvec* a, size_t aoff, const bp_fr
     if (!ctx || !a || !b || !out_le32) return BP_ERR_ARG;
     if (aoff > a->n || n > a->n - aoff || boff > b->n || n > b->n - boff) return BP_ERR_LENGTH;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
-    if ((rc = ctx->scratch.reserve((kInnerBlocks + 2) * 32))) return rc;
+    if ((rc = ctx->scratch.reserve(ctx, (kInnerBlocks + 2) * 32))) return rc;
     auto* part = (ScalarWords*)ctx->scratch.p;
     if (ctx->curve == BP_CURVE_BLS12_381) rc = Ipp<Bls381>::inner(ctx, (const ScalarWords*)a->d + aoff, (const ScalarWords*)b->d + boff, n, part + 1, part);
     else rc = Ipp<Bn254>::inner(ctx, (const ScalarWords*)a->d + aoff, (const ScalarWords*)b->d + boff, n, part + 1, part);
@@ -661,7 +661,7 @@ int bp_vecpoly3_special_inner_product(bp_ctx* ctx, const bp_frvec* const lhs[4],
     if ((rc = same_len(lhs, 4, &n)) || (rc = same_len(rhs, 4, &n2))) return rc;
     if (n != n2) return BP_ERR_LENGTH;
     if ((rc = bp_internal_set_device(ctx))) return rc;
-    if ((rc = ctx->scratch.reserve((6 * kInnerBlocks + 8) * 32))) return rc;
+    if ((rc = ctx->scratch.reserve(ctx, (6 * kInnerBlocks + 8) * 32))) return rc;
     auto* out = (ScalarWords*)ctx->scratch.p;
     auto* part = out + 8;
     unsigned g = blocks_for(n);
@@ -689,7 +689,7 @@ int bp_vecpoly1_inner_product(bp_ctx* ctx, const bp_frvec* const l[2], const bp_
     if ((rc = same_len(l, 2, &n)) || (rc = same_len(r, 2, &n2))) return rc;
     if (n != n2) return BP_ERR_LENGTH;
     if ((rc = bp_internal_set_device(ctx))) return rc;
-    if ((rc = ctx->scratch.reserve((3 * kInnerBlocks + 8) * 32))) return rc;
+    if ((rc = ctx->scratch.reserve(ctx, (3 * kInnerBlocks + 8) * 32))) return rc;
     auto* out = (ScalarWords*)ctx->scratch.p;
     auto* part = out + 8;
     unsigned g = blocks_for(n);
@@ -813,7 +813,7 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     st->blocks = new (std::nothrow) std::vector<std::pair<void*, size_t>>();
     if (!st->blocks) { delete st; return BP_ERR_DEVICE; }
     hipStream_t s = ctx->stream;
-    if ((rc = ctx->flags.reserve(64))) { bp_ipp_state_free(st); return rc; }
+    if ((rc = ctx->flags.reserve(ctx, 64))) { bp_ipp_state_free(st); return rc; }
     uint32_t* flag = (uint32_t*)ctx->flags.p;
     uint32_t host_flag = 0;
     bool ok = st->take(&st->a, n * 32) && st->take(&st->b, n * 32) && st->take(&st->cLR, 64) && st->take(&st->partial, (kInnerBlocks + 1) * 32) &&

@@ -1,10 +1,19 @@
-// bp_host_tail.hpp -- the serial tail of an MSM on the host:  sum_w 2^(off_w) S_w  and the affine normalisation.
+// bp_host_tail.hpp -- the serial tail of an MSM on the host:  sum_r 2^(pos_r) Rec_r  and the affine normalisation.
 //
 // This is the one strictly sequential piece of the pipeline (~255 dependent point doublings; a single GPU lane needs
 // ~2 ms for it).  It runs on the host with 64-bit limbs and unsigned __int128 products (the 30-bit-limb templates of
 // bp_field.cuh are laid out for 32-bit VGPRs and are ~3x slower on a CPU).  Jacobian coordinates (doubling 2M + 5S).
-// Montgomery radix here is 2^(64 NL64); inputs arrive as packed XYZZ records in the DEVICE's Montgomery radix
-// 2^(30 NL) and are rescaled on entry (one multiplication by 2^(64 NL64 - 30 NL) mod p ... folded into to_host()).
+//
+// Round 3: the bucket reduce hands over one record per BIT PLANE of the reduce-thread index (bp_kernels.cuh:
+// k_bucket_reduce) instead of multiplying by the weights on the device, so a 2^20-point MSM arrives as ~200 records instead of 16.
+// The fold therefore had to become cheap per record:
+//   * records arrive in HOST form (bp_curve.cuh: xyzz_lazy_to_host_record): Jacobian (X ZZ^2, Y ZZZ^2, ZZZ), canonical, already
+//     in this file's Montgomery radix 2^(64 N) -- loading one is a copy (rounds 1-2: four radix conversions + four products);
+//   * the Montgomery product is the "no-carry" CIOS for moduli with a clear top bit, fully unrolled (-25 %);
+//   * the records are dealt round-robin to `chains` independent Horner walks (each one: all the doublings, 1/chains of the
+//     additions) that can run on helper threads (bp_internal.hpp: HostPool) and are added at the end; with 4 chains the critical
+//     path of a 208-record fold is 255 doublings + 55 additions instead of 255 + 208;
+//   * the final inversion is a binary extended Euclid (~4x faster than a^(p-2)).
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -14,9 +23,13 @@
 namespace bp {
 namespace host {
 
+typedef unsigned __int128 u128;
+constexpr int kTailMaxRecords = 4096;       // == kMaxRecords of bp_kernels.cuh (this header also builds without HIP)
+
 template <class P>   // P = Field<...> of bp_field.cuh (for the modulus words)
 struct F64 {
     static constexpr int N = (P::NW + 1) / 2;
+    static_assert(P::BITS < 64 * N, "the no-carry product needs a clear top bit");
     uint64_t mod[N], one[N], r2[N], inv;
     F64() {
         for (int i = 0; i < N; i++) mod[i] = (uint64_t)P::Words::MODW[2 * i] | (2 * i + 1 < P::NW ? (uint64_t)P::Words::MODW[2 * i + 1] << 32 : 0);
@@ -39,47 +52,87 @@ struct F64 {
         return true;
     }
     void sub_mod(uint64_t* a) const {
-        unsigned __int128 br = 0;
-        for (int i = 0; i < N; i++) { unsigned __int128 d = (unsigned __int128)a[i] - mod[i] - (uint64_t)br; a[i] = (uint64_t)d; br = (d >> 64) & 1; }
+        uint64_t br = 0;
+        for (int i = 0; i < N; i++) { u128 d = (u128)a[i] - mod[i] - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
     }
-    void add(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
-        unsigned __int128 c = 0;
-        uint64_t t[N];
-        for (int i = 0; i < N; i++) { c += (unsigned __int128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
-        if (c || geq(t)) sub_mod(t);
-        memcpy(r, t, sizeof t);
+    // r = a + b mod p   (inputs < p)
+    inline void add(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
+        uint64_t t[N], d[N], c = 0, br = 0;
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) { u128 s = (u128)a[i] + b[i] + c; t[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) { u128 s = (u128)t[i] - mod[i] - br; d[i] = (uint64_t)s; br = (uint64_t)(s >> 64) & 1; }
+        const bool keep = br && !c;                        // t < p
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) r[i] = keep ? t[i] : d[i];
     }
-    void sub(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
-        uint64_t t[N], br = 0;
-        for (int i = 0; i < N; i++) { unsigned __int128 d = (unsigned __int128)a[i] - b[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-        if (br) { unsigned __int128 c = 0; for (int i = 0; i < N; i++) { c += (unsigned __int128)t[i] + mod[i]; t[i] = (uint64_t)c; c >>= 64; } }
-        memcpy(r, t, sizeof t);
+    inline void sub(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
+        uint64_t t[N], br = 0, c = 0;
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) { u128 d = (u128)a[i] - b[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+        const uint64_t mask = 0 - br;                      // negative: add p back
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) { u128 s = (u128)t[i] + (mod[i] & mask) + c; r[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
     }
-    void mul(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
-        uint64_t t[N + 2] = {};
+    // Montgomery product, CIOS without the (N+1)-th and (N+2)-th accumulator words: valid because the modulus leaves its top bit
+    // clear (El Housni / Botrel, "no-carry" optimisation).  Inputs < p (one of them may be any value < 2^(64N) whose product with
+    // the other stays below p 2^(64N)); output < p.
+    inline void mul(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
+        uint64_t t[N] = {};
+#pragma GCC unroll 8
         for (int i = 0; i < N; i++) {
-            unsigned __int128 c = 0;
-            for (int j = 0; j < N; j++) { c += (unsigned __int128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-            c += t[N]; t[N] = (uint64_t)c; t[N + 1] = (uint64_t)(c >> 64);
-            uint64_t m = t[0] * inv;
-            c = (unsigned __int128)m * mod[0] + t[0]; c >>= 64;
-            for (int j = 1; j < N; j++) { c += (unsigned __int128)m * mod[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-            c += t[N]; t[N - 1] = (uint64_t)c; t[N] = t[N + 1] + (uint64_t)(c >> 64);
+            u128 x = (u128)a[0] * b[i] + t[0];
+            uint64_t A = (uint64_t)(x >> 64);
+            const uint64_t m = (uint64_t)x * inv;
+            u128 y = (u128)m * mod[0] + (uint64_t)x;
+            uint64_t Cc = (uint64_t)(y >> 64);
+#pragma GCC unroll 8
+            for (int j = 1; j < N; j++) {
+                x = (u128)a[j] * b[i] + t[j] + A; A = (uint64_t)(x >> 64);
+                y = (u128)m * mod[j] + (uint64_t)x + Cc; Cc = (uint64_t)(y >> 64);
+                t[j - 1] = (uint64_t)y;
+            }
+            t[N - 1] = Cc + A;
         }
-        if (t[N] || geq(t)) sub_mod(t);
-        memcpy(r, t, N * 8);
+        uint64_t d[N], br = 0;
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) { u128 s = (u128)t[i] - mod[i] - br; d[i] = (uint64_t)s; br = (uint64_t)(s >> 64) & 1; }
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) r[i] = br ? t[i] : d[i];
     }
+    inline void sqr(uint64_t* r, const uint64_t* a) const { mul(r, a, a); }
     bool is_zero(const uint64_t* a) const { uint64_t o = 0; for (int i = 0; i < N; i++) o |= a[i]; return o == 0; }
-    void inverse(uint64_t* r, const uint64_t* a) const {   // a^(p-2)
-        uint64_t e[N]; memcpy(e, mod, sizeof e);
-        uint64_t br = 2;
-        for (int i = 0; i < N && br; i++) { uint64_t o = e[i]; e[i] = o - br; br = o < br; }
-        uint64_t acc[N]; memcpy(acc, one, sizeof acc);
-        for (int i = P::BITS - 1; i >= 0; i--) {
-            mul(acc, acc, acc);
-            if ((e[i >> 6] >> (i & 63)) & 1) mul(acc, acc, a);
+
+    // ---- inversion: binary extended Euclid on plain integers (variable time: the operand is the Z of a public result) ----
+    static bool is_one(const uint64_t* a) { uint64_t o = a[0] ^ 1; for (int i = 1; i < N; i++) o |= a[i]; return o == 0; }
+    static bool ge(const uint64_t* a, const uint64_t* b) { for (int i = N - 1; i >= 0; i--) { if (a[i] != b[i]) return a[i] > b[i]; } return true; }
+    static void shr1(uint64_t* a, uint64_t top = 0) { for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 63); a[N - 1] = (a[N - 1] >> 1) | (top << 63); }
+    static uint64_t add_n(uint64_t* a, const uint64_t* b) { uint64_t c = 0; for (int i = 0; i < N; i++) { u128 s = (u128)a[i] + b[i] + c; a[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } return c; }
+    static void sub_n(uint64_t* a, const uint64_t* b) { uint64_t br = 0; for (int i = 0; i < N; i++) { u128 d = (u128)a[i] - b[i] - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
+    void half_mod(uint64_t* x) const { if (x[0] & 1) { uint64_t c = add_n(x, mod); shr1(x, c); } else shr1(x); }   // x / 2 mod p
+    void sub_modp(uint64_t* x, const uint64_t* y) const {      // x = x - y mod p, both < p
+        if (ge(x, y)) { sub_n(x, y); return; }
+        uint64_t t[N];
+        memcpy(t, mod, sizeof t);
+        sub_n(t, y);
+        add_n(x, t);                                           // x + (p - y) < p
+    }
+    // r = a^-1 (Montgomery in, Montgomery out), a != 0 mod p
+    void inverse(uint64_t* r, const uint64_t* a) const {
+        uint64_t u[N], v[N], x1[N] = {}, x2[N] = {};
+        memcpy(u, a, sizeof u);
+        memcpy(v, mod, sizeof v);
+        x1[0] = 1;
+        while (!is_one(u) && !is_one(v)) {
+            while (!(u[0] & 1)) { shr1(u); half_mod(x1); }
+            while (!(v[0] & 1)) { shr1(v); half_mod(x2); }
+            if (ge(u, v)) { sub_n(u, v); sub_modp(x1, x2); }
+            else { sub_n(v, u); sub_modp(x2, x1); }
         }
-        memcpy(r, acc, sizeof acc);
+        const uint64_t* res = is_one(u) ? x1 : x2;     // (a R)^-1 = a^-1 R^-1 as a plain integer
+        uint64_t t[N];
+        mul(t, res, r2);                               // a^-1 R^-1 * R^2 / R = a^-1
+        mul(r, t, r2);                                 // a^-1 * R^2 / R       = a^-1 R
     }
 };
 
@@ -88,23 +141,18 @@ class Tail {
     using Fp = typename C::Fp;
     using F = F64<Fp>;
     static constexpr int N = F::N;
+public:
     struct Jac { uint64_t x[N], y[N], z[N]; bool inf; };
+private:
     F f;
-    uint64_t dev_to_host[N];   // 2^(64N) * 2^(64N) / 2^(30 NL)  in plain form: mul(x_devmont_plain, k) -> host Montgomery form
 
-    // canonical words of a device-Montgomery residue (x * 2^(30 NL)) -> host Montgomery (x * 2^(64 N))
-    void load(uint64_t* out, const uint32_t* words) const {
-        uint64_t t[N] = {};
-        for (int i = 0; i < Fp::NW; i++) t[i / 2] |= (uint64_t)words[i] << (32 * (i & 1));
-        f.mul(out, t, dev_to_host);
-    }
     void dbl(Jac& p) const {   // dbl-2009-l, a = 0
         if (p.inf) return;
         uint64_t A[N], B[N], Cc[N], D[N], E[N], Fq[N], t[N];
-        f.mul(A, p.x, p.x); f.mul(B, p.y, p.y); f.mul(Cc, B, B);
-        f.add(t, p.x, B); f.mul(t, t, t); f.sub(t, t, A); f.sub(t, t, Cc); f.add(D, t, t);
+        f.sqr(A, p.x); f.sqr(B, p.y); f.sqr(Cc, B);
+        f.add(t, p.x, B); f.sqr(t, t); f.sub(t, t, A); f.sub(t, t, Cc); f.add(D, t, t);
         f.add(E, A, A); f.add(E, E, A);
-        f.mul(Fq, E, E);
+        f.sqr(Fq, E);
         uint64_t x3[N], y3[N], z3[N];
         f.add(t, D, D); f.sub(x3, Fq, t);
         f.mul(z3, p.y, p.z); f.add(z3, z3, z3);
@@ -117,36 +165,31 @@ class Tail {
         if (q.inf) return;
         if (p.inf) { p = q; return; }
         uint64_t z1z1[N], z2z2[N], u1[N], u2[N], s1[N], s2[N], h[N], i[N], j[N], rr[N], v[N], t[N];
-        f.mul(z1z1, p.z, p.z); f.mul(z2z2, q.z, q.z);
+        f.sqr(z1z1, p.z); f.sqr(z2z2, q.z);
         f.mul(u1, p.x, z2z2); f.mul(u2, q.x, z1z1);
         f.mul(s1, p.y, q.z); f.mul(s1, s1, z2z2);
         f.mul(s2, q.y, p.z); f.mul(s2, s2, z1z1);
         f.sub(h, u2, u1); f.sub(rr, s2, s1);
         if (f.is_zero(h)) { if (f.is_zero(rr)) { dbl(p); return; } p.inf = true; return; }
         f.add(rr, rr, rr);
-        f.add(i, h, h); f.mul(i, i, i);
+        f.add(i, h, h); f.sqr(i, i);
         f.mul(j, h, i); f.mul(v, u1, i);
         uint64_t x3[N], y3[N], z3[N];
-        f.mul(x3, rr, rr); f.sub(x3, x3, j); f.add(t, v, v); f.sub(x3, x3, t);
+        f.sqr(x3, rr); f.sub(x3, x3, j); f.add(t, v, v); f.sub(x3, x3, t);
         f.sub(t, v, x3); f.mul(y3, rr, t); f.mul(t, s1, j); f.add(t, t, t); f.sub(y3, y3, t);
-        f.add(z3, p.z, q.z); f.mul(z3, z3, z3); f.sub(z3, z3, z1z1); f.sub(z3, z3, z2z2); f.mul(z3, z3, h);
+        f.add(z3, p.z, q.z); f.sqr(z3, z3); f.sub(z3, z3, z1z1); f.sub(z3, z3, z2z2); f.mul(z3, z3, h);
         memcpy(p.x, x3, sizeof x3); memcpy(p.y, y3, sizeof y3); memcpy(p.z, z3, sizeof z3);
     }
-    // XYZZ (x = X/ZZ, y = Y/ZZZ) -> Jacobian with Z = ZZZ/ZZ ... avoided: use X' = X*ZZ, Y' = Y*ZZZ, Z' = ZZ*... see below
-    Jac from_record(const XyzzPacked<C>& r) const {
-        Jac p; p.inf = false;
-        uint64_t X[N], Y[N], ZZ[N], ZZZ[N];
-        load(X, r.x.w); load(Y, r.y.w); load(ZZ, r.zz.w); load(ZZZ, r.zzz.w);
-        if (f.is_zero(ZZ)) { p.inf = true; memset(p.x, 0, sizeof p.x); memset(p.y, 0, sizeof p.y); memset(p.z, 0, sizeof p.z); return p; }
-        // With z^2 = ZZ, z^3 = ZZZ: choose Jacobian Z = ZZ * ZZZ (= z^5):  X_J = x Z^2 = X ZZ^4... simpler and exact:
-        // Z := ZZZ ... Z^2 = ZZ^3, Z^3 = ZZZ^3.  X_J = (X/ZZ) ZZ^3 = X ZZ^2 ;  Y_J = (Y/ZZZ) ZZZ^3 = Y ZZZ^2.
-        uint64_t t[N];
-        f.mul(t, ZZ, ZZ); f.mul(p.x, X, t);
-        f.mul(t, ZZZ, ZZZ); f.mul(p.y, Y, t);
-        memcpy(p.z, ZZZ, sizeof ZZZ);
+    // host-form record (see the header of this file): three canonical coordinates in this radix, Z in the `zz` slot; Z = 0 is the identity
+    static Jac from_record(const XyzzPacked<C>& r) {
+        Jac p;
+        memset(&p, 0, sizeof p);
+        memcpy(p.x, r.x.w, 4 * Fp::NW); memcpy(p.y, r.y.w, 4 * Fp::NW); memcpy(p.z, r.zz.w, 4 * Fp::NW);
+        uint64_t o = 0;
+        for (int i = 0; i < N; i++) o |= p.z[i];
+        p.inf = o == 0;
         return p;
     }
-
     static bool is_identity_record(const XyzzPacked<C>& r) {
         uint32_t o = 0;
         for (int i = 0; i < Fp::NW; i++) o |= r.zz.w[i];
@@ -154,54 +197,72 @@ class Tail {
     }
 
 public:
-    Tail() {
-        // k = 2^(128 N - 30 NL) mod p, plain integer:  mul(a, k) = a * k / 2^(64N) = a * 2^(64N) / 2^(30NL)
-        uint64_t t[N] = {};
-        t[0] = 1;
-        const int e = 128 * N - LB * Fp::NL;
-        for (int i = 0; i < e; i++) {
-            uint64_t carry = t[N - 1] >> 63;
-            for (int j = N - 1; j > 0; j--) t[j] = (t[j] << 1) | (t[j - 1] >> 63);
-            t[0] <<= 1;
-            if (carry || f.geq(t)) f.sub_mod(t);
-        }
-        memcpy(dev_to_host, t, sizeof t);
+    static constexpr int kMaxChains = 8;
+    Tail() {}
+
+    // an affine point (canonical LE words, plain integers) as a host-form record: (x R, y R, R)
+    void record_from_affine(const uint32_t* xw, const uint32_t* yw, XyzzPacked<C>* out) const {
+        memset(out, 0, sizeof *out);
+        uint32_t any = 0;
+        for (int i = 0; i < Fp::NW; i++) any |= xw[i] | yw[i];
+        if (!any) return;
+        uint64_t x[N] = {}, y[N] = {}, t[N];
+        for (int i = 0; i < Fp::NW; i++) { x[i / 2] |= (uint64_t)xw[i] << (32 * (i & 1)); y[i / 2] |= (uint64_t)yw[i] << (32 * (i & 1)); }
+        f.mul(t, x, f.r2); memcpy(out->x.w, t, 4 * Fp::NW);
+        f.mul(t, y, f.r2); memcpy(out->y.w, t, 4 * Fp::NW);
+        memcpy(out->zz.w, f.one, 4 * Fp::NW);
     }
 
-    // result = sum_r 2^(pos[r]) (sum_s rec[s * nrec + r]) as canonical little-endian x || y (all-zero = identity): Horner over the
-    // records in descending bit position, pos[r] - pos[next] doublings in between (~255 in all, whatever the record count).
-    void fold(const XyzzPacked<C>* rec, size_t sets, int nrec, const uint16_t* pos, uint8_t* out_le) const {
-        Jac acc; acc.inf = true;
-        memset(acc.x, 0, sizeof acc.x); memset(acc.y, 0, sizeof acc.y); memset(acc.z, 0, sizeof acc.z);
+    // chain `k` of `chains`: Horner over every chains-th non-identity record (in descending bit position), all the way down to bit 0
+    void fold_chain(const XyzzPacked<C>* rec, size_t sets, int nrec, const uint16_t* pos, int k, int chains, Jac* out) const {
+        Jac acc;
+        memset(&acc, 0, sizeof acc);
+        acc.inf = true;
         // order of the records by descending position (bucket lists over the bit positions)
         constexpr int kMaxPos = 600;
         int head[kMaxPos + 1];
         for (int p = 0; p <= kMaxPos; p++) head[p] = -1;
-        int* next = new int[nrec > 0 ? nrec : 1];
-        for (int r = 0; r < nrec; r++) { int p = pos[r] <= kMaxPos ? pos[r] : kMaxPos; next[r] = head[p]; head[p] = r; }
-        int cur = -1;
-        for (int p = kMaxPos; p >= 0; p--) {
+        int next[kTailMaxRecords];                             // nrec <= kMaxRecords (msm_geom refuses more): no allocation on this path
+        if (nrec > kTailMaxRecords) nrec = kTailMaxRecords;
+        int top = 0;
+        for (int r = 0; r < nrec; r++) { int p = pos[r] <= kMaxPos ? pos[r] : kMaxPos; next[r] = head[p]; head[p] = r; if (p > top) top = p; }   // positions are < 300 by construction (fr_bits + c)
+        int cur = -1, seen = 0;
+        for (int p = top; p >= 0; p--) {
             for (int r = head[p]; r >= 0; r = next[r]) {
                 bool any = false;
                 for (size_t s = 0; s < sets && !any; s++) any = !is_identity_record(rec[s * (size_t)nrec + r]);
                 if (!any) continue;
+                if ((seen++ % chains) != k) continue;          // dealt round-robin among the chains (identity records are not dealt)
                 if (cur >= 0) for (int i = 0; i < cur - p; i++) dbl(acc);
                 cur = p;
                 for (size_t s = 0; s < sets; s++) add(acc, from_record(rec[s * (size_t)nrec + r]));
             }
         }
-        delete[] next;
         for (int i = 0; i < cur; i++) dbl(acc);
+        *out = acc;
+    }
+
+    // sum of the chains' partial results -> canonical little-endian x || y (all-zero = identity)
+    void finish(const Jac* parts, int chains, uint8_t* out_le) const {
+        Jac acc = parts[0];
+        for (int k = 1; k < chains; k++) add(acc, parts[k]);
         const int fb = 4 * Fp::NW;
         memset(out_le, 0, 2 * fb);
         if (acc.inf) return;
         uint64_t zi[N], zi2[N], zi3[N], x[N], y[N], onep[N] = {};
         f.inverse(zi, acc.z);
-        f.mul(zi2, zi, zi); f.mul(zi3, zi2, zi);
+        f.sqr(zi2, zi); f.mul(zi3, zi2, zi);
         f.mul(x, acc.x, zi2); f.mul(y, acc.y, zi3);
         onep[0] = 1;
         f.mul(x, x, onep); f.mul(y, y, onep);   // out of Montgomery form
         memcpy(out_le, x, fb); memcpy(out_le + fb, y, fb);
+    }
+
+    // result = sum_r 2^(pos[r]) (sum_s rec[s * nrec + r]): single chain on the calling thread
+    void fold(const XyzzPacked<C>* rec, size_t sets, int nrec, const uint16_t* pos, uint8_t* out_le) const {
+        Jac part;
+        fold_chain(rec, sets, nrec, pos, 0, 1, &part);
+        finish(&part, 1, out_le);
     }
 };
 

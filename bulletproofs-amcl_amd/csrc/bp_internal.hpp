@@ -15,27 +15,28 @@
 #include "../../include/bpmsm.h"
 #include "bp_kernels.cuh"
 
+// Environment variables: the library reads exactly two, both DIAGNOSTIC (they add stderr output / synchronisation, never change a
+// result): BP_VERBOSE (name the failing HIP call) and BP_TRACE (synchronise and log after every pipeline stage).  Everything that
+// can change what the pipeline does is a validated per-context knob (bp_ctx_set_tuning, include/bpmsm.h).
+static inline bool bp_verbose_on() { static const bool on = getenv("BP_VERBOSE") != nullptr; return on; }
+static inline bool bp_trace_on() { static const bool on = getenv("BP_TRACE") != nullptr; return on; }
+
 #define HIPCHK(expr)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (expr);                                                                              \
         if (e_ != hipSuccess) {                                                                              \
-            if (getenv("BP_VERBOSE")) fprintf(stderr, "[bpmsm] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (bp_verbose_on()) fprintf(stderr, "[bpmsm] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
             return BP_ERR_DEVICE;                                                                            \
         }                                                                                                    \
     } while (0)
+
+struct bp_ctx;
 
 // ------------------------------------------------------------------------------------------------ handles
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return BP_OK;
-        if (p) { if (hipFree(p) != hipSuccess) return BP_ERR_DEVICE; p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return BP_ERR_DEVICE; }
-        cap = want;
-        return BP_OK;
-    }
+    inline int reserve(bp_ctx* ctx, size_t bytes);   // defined after bp_ctx: a failed hipMalloc gives the pool's cached blocks back and retries once
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -66,8 +67,9 @@ struct DevPool {
         }
         void* p = nullptr;
         if (hipMalloc(&p, c) != hipSuccess) {
+            (void)hipGetLastError();                                              // the failure must not surface at the next kernel launch's error check
             trim();                                                               // give cached blocks back and retry once
-            if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+            if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         refs++;
         return p;
@@ -85,10 +87,13 @@ struct DevPool {
     }
     void trim() {
         std::lock_guard<std::mutex> lk(mu);
-        (void)hipSetDevice(device);
+        int prev = -1;
+        (void)hipGetDevice(&prev);                                                // a late put() from a handle that outlived its context runs on
+        (void)hipSetDevice(device);                                               // the caller's thread: leave its current device as it was
         for (auto& kv : free_) for (void* p : kv.second) (void)hipFree(p);
         free_.clear();
         cached_bytes = 0;
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
     void release() { if (--refs == 0) destroy(); }     // the context's own reference
     void destroy() { trim(); delete this; }
@@ -136,12 +141,84 @@ struct HostWorker {
     }
 };
 
+// A few helper threads per context for the host tail's independent Horner chains (bp_host_tail.hpp): run(njobs, fn) executes
+// fn(0) .. fn(njobs - 1) on the helpers AND the calling thread and returns when all are done.  Threads start on first use and park
+// on a condition variable in between.  One run at a time per pool (a context is used by one host thread).
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void(int)>* fn = nullptr;
+    std::atomic<int> njobs{0};
+    std::atomic<int> next{0};
+    int pending = 0;
+    uint64_t epoch = 0;
+    bool quit = false;
+    static constexpr int kMaxHelpers = 7;
+    void ensure(int helpers) {
+        if (helpers > kMaxHelpers) helpers = kMaxHelpers;
+        while ((int)th.size() < helpers) {
+            try { th.emplace_back([this] { worker(); }); } catch (...) { return; }     // fewer helpers: the caller's thread does the rest
+        }
+    }
+    void drain() {                                             // claim and run jobs until none is left
+        for (;;) {
+            const int j = next.fetch_add(1);
+            if (j >= njobs.load()) return;
+            (*fn)(j);
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    void run(int n, const std::function<void(int)>& f, int helpers) {
+        if (n <= 0) return;
+        if (n == 1 || helpers <= 0) { for (int j = 0; j < n; j++) f(j); return; }
+        ensure(helpers < n - 1 ? helpers : n - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f; njobs.store(n); pending = n; epoch++;
+            next.store(0);                                     // last: a helper that claims a job sees fn / njobs of THIS run
+        }
+        cv_job.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return pending == 0; });
+        njobs.store(0);                                        // late wakers find nothing to claim
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return quit || epoch != seen; });
+                if (quit) return;
+                seen = epoch;
+            }
+            drain();
+        }
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_job.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
+// Engineering knobs of the MSM pipeline (bp_ctx_set_tuning): 0 = automatic.  Every value is validated when it is set.
+struct bp_tuning {
+    uint32_t tile = 0;          // scalars per binning block: a multiple of 256 in [256, 16384]
+    uint32_t reduce_m = 0;      // buckets per bucket-reduce thread: a power of two in [1, 16384]
+    uint64_t task_target = 0;   // task count the accumulate aims at: [1024, 2^28]
+    bool small_msm = true;      // single-launch path for n <= 512
+};
+
 struct bp_ctx {
     int curve = 0;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int c_override = 0;
+    bp_tuning tuning;
     bool timing = false;
     bool pending = false;               // bp_msm_g1_begin issued, bp_msm_g1_end not yet called
     size_t pending_n = 0;
@@ -153,25 +230,34 @@ struct bp_ctx {
     DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
-    hipEvent_t ev[8] = {};
-    hipEvent_t ev_acc[16] = {};         // start / end of each window group's accumulate launch
-    hipEvent_t ev_sync[2] = {};         // fork / join of the auxiliary stream (no timing)
-    hipStream_t aux_stream = nullptr;   // second front stream of the window-group pipeline (bp_capi.hip: msm_windows)
-    hipStream_t tail_stream[8] = {};    // one per window group: combine / bucket reduce / window sums beside the next accumulates
-    hipEvent_t ev_tail[8] = {};
-    int last_groups = 0;
+    hipEvent_t ev[8] = {};              // stage boundaries of the last MSM (created on first use, only when timing is on)
     bool ev_ready = false;
     float last_ms[8] = {};
     int last_ms_n = 0;
     DevPool* pool = nullptr;            // vectors and temporaries (see DevPool)
     HostWorker worker;
+    HostPool tail_pool;                 // helper threads of the host tail (independent Horner chains)
+    int tail_chains = 0;                // 0 = automatic (4 chains when a fold has >= 48 records), 1 = single chain
     bp_ctx* helper[2] = {nullptr, nullptr};   // lazily created sibling contexts (own stream + workspace) for independent MSMs in flight
     hipEvent_t ev_fork = nullptr;             // "everything queued on this context so far" for the siblings' streams
     DevBuf flags;                       // 64 B of device error flags (point / scalar validation)
     // geometry of the MSM queued by bp_msm_g1_begin (consumed by _end; bp_ctx_set_window_bits in between cannot disturb it)
     int pending_nrec = 0;
-    uint16_t pending_rpos[bp::kRecPerWin * bp::kMaxWindows] = {};
+    uint16_t pending_rpos[bp::kMaxRecords] = {};
 };
+
+inline int DevBuf::reserve(bp_ctx* ctx, size_t bytes) {
+    if (bytes <= cap) return BP_OK;
+    if (p) { if (hipFree(p) != hipSuccess) return BP_ERR_DEVICE; p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx && ctx->pool) ctx->pool->trim();       // gigabytes of cached vector blocks must not make a larger workspace fail
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return BP_ERR_DEVICE; }
+    }
+    cap = want;
+    return BP_OK;
+}
 
 // RAII block from a context's pool (temporaries inside one call)
 struct PoolBlock {
@@ -196,6 +282,11 @@ struct bp_g1vec {
     int device;
     DevPool* pool = nullptr;   // owned blocks come from (and return to) this pool
     size_t cap = 0;
+    // bp_g1vec_device_ptr was called: the raw pointer may be in use on streams this library does not know (torch, RCCL, a view on
+    // another context), so freeing the vector waits for the whole device first (what hipFree used to do) instead of relying on the
+    // owner's stream order.  Vectors that never leave the library keep the synchronisation-free path.
+    bool exported = false;
+    struct bp_g1table* table = nullptr;   // window-multiples table built by bp_g1vec_precompute (owned; freed with the vector)
 };
 struct bp_frvec {
     bp_ctx* ctx;
@@ -205,7 +296,19 @@ struct bp_frvec {
     int device;
     DevPool* pool = nullptr;
     size_t cap = 0;
+    bool exported = false;     // see bp_g1vec
 };
+
+// Window-multiples table of a resident vector (bp_g1vec_precompute): rows[w * n + i] = 2^(c w) P_i, affine, packed.
+struct bp_g1table {
+    DevPool* pool = nullptr;
+    int device = 0;
+    void* d = nullptr;       // W * n packed affine rows (window 0 = a copy of the vector itself)
+    size_t cap = 0;
+    size_t n = 0;
+    int c = 0, W = 0;
+};
+extern "C" void bp_internal_table_free(bp_g1table* t);
 
 static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
 static inline bool curve_ok(int curve) { return curve == BP_CURVE_BLS12_381 || curve == BP_CURVE_BN254; }
@@ -219,11 +322,10 @@ static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
 }
 
 
-// BP_TRACE=1: synchronise and log after every stage (debugging aid; off by default).
+// BP_TRACE=1: synchronise and log after every stage (debugging aid; off by default; changes timing, never results).
 #define BP_TRACE_SYNC(ctx_, what)                                                                      \
     do {                                                                                               \
-        static const bool on_ = getenv("BP_TRACE") != nullptr;                                         \
-        if (on_) {                                                                                     \
+        if (bp_trace_on()) {                                                                           \
             hipError_t te_ = hipStreamSynchronize((ctx_)->stream);                                     \
             fprintf(stderr, "[bpmsm trace] %s -> %s\n", what, hipGetErrorString(te_));                 \
             fflush(stderr);                                                                            \
@@ -231,11 +333,13 @@ static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
     } while (0)
 
 // MSM over raw resident device arrays (n > 0 or n == 0 -> identity); defined in bp_capi.hip.
-int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le);
+int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le, const bp_g1table* tb = nullptr);
+// window-multiples table over n resident points (pool block; bp_internal_table_free)
+int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp_g1table** out);
 // sibling contexts for independent MSMs in flight (bp_capi.hip)
 extern "C" bp_ctx* bp_internal_helper(bp_ctx* ctx, int k);
 extern "C" int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling);
 // nnz = non-zero scalars per set if known (0: assume n)
 int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
-                     size_t nnz);
+                     size_t nnz, const bp_g1table* tb = nullptr);
 int bp_internal_set_device(const bp_ctx* ctx);

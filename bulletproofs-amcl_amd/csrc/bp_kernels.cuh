@@ -54,10 +54,22 @@ struct WinTab {
     uint8_t fbits[kMaxWindows];        // fine bits of a bucket id: min(8, cw - 1); the rest are the coarse bin
     uint16_t hoff[kMaxWindows + 1];    // first coarse-bin row of window w in the tile histogram (hoff[W] = rows)
     uint16_t rboff[kMaxWindows + 1];   // first block of window w in the (compact, 1-D) grid of k_bucket_reduce
-    uint8_t mw[kMaxWindows];           // buckets per reduce thread in window w (the last window group uses a shorter chain)
+    uint8_t lgm[kMaxWindows];          // log2 of the buckets per reduce thread in window w (a power of two, <= the window's buckets)
+    // Merged mode (MSM over a vector with a window-multiples table, bp_g1vec_precompute): every window of a scalar set drops its
+    // entries into the SAME 2^(c-1) buckets, the entry of (window w, point i) naming table row (w % W1) * n + i = 2^(c w) P_i.
+    // boff[w] / hoff[w] are then per SET (equal for all its windows) and a (window, tile) pair is its own column of the tile
+    // histogram: column (w % W1) * ntiles + tile of ntiles * W1.
+    uint8_t merged;
+    uint16_t W1;                       // windows per scalar set
+    uint16_t roff[kMaxWindows + 1];    // first tail record of window w (bucket pipeline: 1 + log2(threads of the window) records)
     ScalarWords bias;   // H = sum_w (2^(cw-1) - 1) 2^off[w]
 };
-constexpr int kRecPerWin = 1;          // tail records per window handed to the host (record r carries weight 2^rpos[r], bp_capi.hip)
+// Tail records handed to the host (record r carries weight 2^rpos[r], bp_capi.hip).  The bucket pipeline emits, per window,
+// the plain weighted sum of the per-thread segments plus one "bit-plane" record per bit of the reduce-thread index (see
+// k_bucket_reduce); the single-launch small MSM emits one record per window.
+constexpr int kMaxRecPerWin = 16;      // 1 + log2(2^15 buckets / 1 per thread)
+constexpr int kMaxRecords = 4096;      // cap on W * records per window (checked in msm_geom)
+constexpr int kPartPerBlock = 10;      // k_bucket_reduce output per block: TRI, RUN, planes of the 8 thread-index bits
 
 constexpr int kTile = 2048;            // scalars per block in the binning passes (8 per lane) for large MSMs; smaller ones use smaller tiles
                                        // (a multiple of kBlock) so that the passes still have a few hundred blocks (bp_capi.hip)
@@ -95,7 +107,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t
 static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords* __restrict__ scalars, const ScalarWords* __restrict__ scalars2, size_t n,
                                                              WinTab tab, uint32_t ntiles, uint32_t tile, uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
     __shared__ uint32_t lh[kMaxBinRows];
-    const uint32_t rows = tab.hoff[tab.W];
+    const bool mg = tab.merged != 0;
+    const uint32_t mbins = 1u << (tab.cw[0] - 1 - tab.fbits[0]);          // merged: coarse bins of a set (same for every window)
+    const uint32_t rows = mg ? (uint32_t)tab.W * mbins : tab.hoff[tab.W];  // LDS rows: one histogram per WINDOW in both modes
     for (uint32_t k = threadIdx.x; k < rows; k += kBlock) lh[k] = 0;
     __syncthreads();
     size_t base = (size_t)blockIdx.x * tile;
@@ -126,14 +140,22 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
                     q[3] >>= c;
                     code[(size_t)w * n + i] = (uint16_t)raw;
                     int d = (int)raw - ((1 << (c - 1)) - 1);
-                    if (d != 0) atomicAdd(&lh[tab.hoff[w] + (((uint32_t)(d < 0 ? -d : d) - 1) >> tab.fbits[w])], 1u);
+                    if (d != 0) atomicAdd(&lh[(mg ? (uint32_t)w * mbins : (uint32_t)tab.hoff[w]) + (((uint32_t)(d < 0 ? -d : d) - 1) >> tab.fbits[w])], 1u);
                 }
             }
         }
       }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < rows; k += kBlock) tile_hist[(size_t)k * ntiles + blockIdx.x] = lh[k];
+    if (!mg) {
+        for (uint32_t k = threadIdx.x; k < rows; k += kBlock) tile_hist[(size_t)k * ntiles + blockIdx.x] = lh[k];
+    } else {
+        const size_t cols = (size_t)ntiles * tab.W1;
+        for (uint32_t k = threadIdx.x; k < rows; k += kBlock) {
+            const uint32_t w = k / mbins, bin = k - w * mbins;
+            tile_hist[(size_t)(tab.hoff[w] + bin) * cols + (size_t)(w % tab.W1) * ntiles + blockIdx.x] = lh[k];
+        }
+    }
 }
 
 // grid = (ntiles, W).  tile_off = scanned tile_hist.  Writes (code, point index) pairs grouped by coarse bin -- as ONE 8-byte record
@@ -144,12 +166,16 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
     __shared__ uint32_t lcur[128];
     const int w = w0 + (int)blockIdx.y;
     const int c = tab.cw[w], fb = tab.fbits[w];
-    const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
-    for (uint32_t k = threadIdx.x; k < nbins; k += kBlock) lcur[k] = tile_off[(size_t)(tab.hoff[w] + k) * ntiles + blockIdx.x];
+    const bool mg = tab.merged != 0;
+    // merged: the bins are those of the SET's 2^(c-1) buckets (its first window has the full width; the last one may be narrower)
+    const uint32_t nbins = mg ? 1u << (tab.cw[(w / tab.W1) * tab.W1] - 1 - fb) : (uint32_t)(tab.hoff[w + 1] - tab.hoff[w]);
+    const size_t cols = mg ? (size_t)ntiles * tab.W1 : ntiles, col = mg ? (size_t)(w % tab.W1) * ntiles + blockIdx.x : blockIdx.x;
+    for (uint32_t k = threadIdx.x; k < nbins; k += kBlock) lcur[k] = tile_off[(size_t)(tab.hoff[w] + k) * cols + col];
     __syncthreads();
     size_t base = (size_t)blockIdx.x * tile;
     const uint32_t half1 = (1u << (c - 1)) - 1;
     const uint32_t per = tile / kBlock;
+    const uint32_t row0 = mg ? (uint32_t)(w % tab.W1) * (uint32_t)n : 0u;      // merged: the entry names a row of the window-multiples table
     for (uint32_t e0 = 0; e0 < per; e0 += kFineBatch) {      // kFineBatch codes per lane in flight
         uint32_t raw[kFineBatch];
 #pragma unroll
@@ -162,7 +188,7 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
             int d = (int)raw[u] - (int)half1;
             if (d != 0) {
                 uint32_t pos = atomicAdd(&lcur[((uint32_t)(d < 0 ? -d : d) - 1) >> fb], 1u);
-                tmp_rec[pos] = make_uint2((uint32_t)(base + (size_t)(e0 + u) * kBlock + threadIdx.x), raw[u]);
+                tmp_rec[pos] = make_uint2(row0 + (uint32_t)(base + (size_t)(e0 + u) * kBlock + threadIdx.x), (uint32_t)d);     // (row, signed digit)
             }
         }
     }
@@ -177,22 +203,22 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
     const int w = w0 + (int)blockIdx.y;
     const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
     if (blockIdx.x >= nbins) return;
-    const int c = tab.cw[w], fb = tab.fbits[w];
+    const int fb = tab.fbits[w];
     const uint32_t row = tab.hoff[w] + blockIdx.x, rows = tab.hoff[tab.W];
     const uint32_t lo = tile_off[(size_t)row * ntiles];
     const uint32_t hi = row + 1 < rows ? tile_off[(size_t)(row + 1) * ntiles] : *total;
-    const uint32_t fmask = (1u << fb) - 1, half1 = (1u << (c - 1)) - 1;
+    const uint32_t fmask = (1u << fb) - 1;
     lh[threadIdx.x] = 0;
     __syncthreads();
     // kFineBatch records per lane are loaded before any of them is used: the loop is otherwise a chain of (load, LDS atomic) pairs
     // paced by the load latency (32 dependent round trips per pass for an 8192-record bin)
     for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += kFineBatch * kBlock) {
-        uint32_t cd[kFineBatch];
+        int dd[kFineBatch];
 #pragma unroll
-        for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; cd[u] = j < hi ? tmp_rec[j].y : half1; }   // half1 = digit 0 = not an element
+        for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; dd[u] = j < hi ? (int)tmp_rec[j].y : 0; }   // digit 0 = not an element
 #pragma unroll
         for (int u = 0; u < kFineBatch; u++) {
-            int d = (int)cd[u] - (int)half1;
+            const int d = dd[u];
             if (d != 0) atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
         }
     }
@@ -209,10 +235,10 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
     for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += kFineBatch * kBlock) {
         uint2 rec[kFineBatch];
 #pragma unroll
-        for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; rec[u] = j < hi ? tmp_rec[j] : make_uint2(0u, half1); }
+        for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; rec[u] = j < hi ? tmp_rec[j] : make_uint2(0u, 0u); }
 #pragma unroll
         for (int u = 0; u < kFineBatch; u++) {
-            int d = (int)rec[u].y - (int)half1;
+            const int d = (int)rec[u].y;
             if (d != 0) {
                 uint32_t pos = atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
                 idx[pos] = rec[u].x | (d < 0 ? 0x80000000u : 0u);
@@ -489,87 +515,123 @@ __global__ void __launch_bounds__(kBlock) k_combine_heavy(const uint32_t* __rest
     }
 }
 
-// small * p by double-and-add (small < 2^16)
+// ---------------------------------------------------------------------------------------------- bit-plane trees
+// LDS holds `nplain + 1` arrays of `live` (a power of two <= pitch) packed lazy points: array 0 (the "plane source" X) at
+// lds[0 .. live), plain array a >= 1 at lds[a * pitch ..).  After the call
+//     lds[0]         = sum of X                          lds[a * pitch] = sum of plain array a
+//     lds[1 << k]    = sum of the X[i] with bit k of i set   (k < log2 live)      -- the "bit planes" of X
+// in log2(live) steps of ONE dependent addition each: at stride s the upper half of X is not consumed, it stays where it is and
+// becomes the array of plane log2(s), which is then summed like any other array by the following steps.  All arrays alive at a
+// step have the same length 2s, so the step is "slot[b + i] += slot[b + i + s]" over a list of bases b; item q of the step is
+// (base index q / s, i = q % s) and the threads share the items (one per thread while they fit: (nplain + 1 + born) * s <= 256).
 template <class C>
-__device__ __forceinline__ Xyzz<C> xyzz_mul_small(uint32_t k, const Xyzz<C>& p) {
-    Xyzz<C> acc = xyzz_inf<C>();
-    if (k == 0) return acc;
-    int top = 31 - __clz(k);
-    for (int i = top; i >= 0; i--) {
-        acc = xyzz_dbl(acc);
-        if ((k >> i) & 1) acc = xyzz_add(acc, p);
-    }
-    return acc;
-}
-
-// small * p by double-and-add (small < 2^16)
-template <class C>
-__device__ __forceinline__ XyzzLazy<C> xyzz_mul_small(uint32_t k, const XyzzLazy<C>& p) {
-    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
-    if (k == 0) return acc;
+__device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pitch, int nplain, bool planes = true) {
+    int born = 0;
 #pragma unroll 1
-    for (int i = 31 - __clz(k); i >= 0; i--) {
-        acc = xyzz_lazy_dbl(acc);
-        if ((k >> i) & 1) acc = xyzz_lazy_add(acc, p);
+    for (int s = live >> 1; s >= 1; s >>= 1, born += planes ? 1 : 0) {
+        const int nitems = (nplain + 1 + born) * s;
+#pragma unroll 1
+        for (int q = (int)threadIdx.x; q < nitems; q += kBlock) {
+            const int u = q / s, i = q - u * s;
+            // u = 0: X itself; 1 .. born: the plane born u steps ago ... listed oldest first: plane j (born at stride live >> (j + 1)) sits at that stride
+            const int base = u == 0 ? 0 : u <= born ? (live >> u) : (u - born) * pitch;
+            XyzzLazy<C> a = xyzz_lazy_unpack(lds[base + i]);
+            a = xyzz_lazy_add(a, xyzz_lazy_unpack(lds[base + i + s]));
+            lds[base + i] = xyzz_lazy_pack(a);
+        }
+        __syncthreads();
     }
-    return acc;
 }
 
 // grid = tab.rboff[W] blocks, window w owning blocks rboff[w] .. rboff[w+1]-1 (exactly the blocks that have buckets: with a
 // 2-D grid padded to the widest window, the blocks that exit at once skewed the dispatch and some CUs ran two of these long
 // dependent chains back to back -- 1.00 ms instead of 0.54 ms at n = 2^16, c = 14; profiles/r01_reduce_grid_*.txt).
-// Thread t of window w owns bucket values (t*m, (t+1)*m], i.e. local bucket indices t*m .. t*m + m - 1, and produces
-//   sum_j (t*m + j + 1) * bucket[t*m + j]  =  t*m * run + tri.
+// Thread t of window w owns the m = 2^lgm consecutive buckets t*m .. t*m + m - 1 (bucket j <-> weight j + 1) and computes
+//     run_t = sum_i bucket[t*m + i]          tri_t = sum_i (i + 1) bucket[t*m + i]          (2m dependent additions)
+// so that the window sum is   sum_t tri_t  +  m * sum_t t * run_t.
+// Rounds 1-2 multiplied run_t by t*m on the spot (double-and-add: ~22 more dependent point operations per thread, half of the
+// kernel).  Now the weight t is never applied on the device:  sum_t t run_t = sum_k 2^k A_k  with A_k = sum of the run_t whose t
+// has bit k set, and the A_k come out of the SAME tree that sums the block (plane_tree above) at no extra depth.  Each A_k leaves
+// as its own tail record with bit position off_w + lgm + k; the host's Horner walk over bit positions (bp_host_tail.hpp) passes
+// every position anyway, so a plane costs it one addition (~0.5 us) where the device paid 16 us per dependent step.
+// Per block:  partial[bid * kPartPerBlock + 0] = sum tri, [1] = sum run, [2 + k] = plane of thread-index bit k (k < log2 live).
 // Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
-// (Round 2 tried to replace this by plain "digit sums" of the bucket values -- 2 independent additions per bucket, ~25 dependent
-// steps instead of ~46, weights left to the host's doubling chain.  It lost: every dependent step of a lone wave costs 17-20 us
-// whatever the formulation, the wave-level trees idle most lanes, and each extra ~50 KB of inlined addition code a kernel
-// touches costs ~0.1-0.2 ms of cold instruction fetch per launch (profiles/r02_digit_sum_experiment.txt).  One balanced wave
-// per SIMD running this chain is the fastest form measured.)
+// (Round 2 tried plain "digit sums" of the bucket values instead -- lost: profiles/r02_digit_sum_experiment.txt.)
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
-                                                          const uint32_t* __restrict__ ntasks, WinTab tab, uint32_t blk0,
+                                                          const uint32_t* __restrict__ ntasks, WinTab tab,
                                                           XyzzPacked<C>* __restrict__ partial) {
-    __shared__ XyzzPacked<C> lds[kBlock];
-    const uint32_t bid = blk0 + blockIdx.x;          // block id in the all-windows grid (a window group launches its own slice)
+    __shared__ XyzzPacked<C> lds[2 * kBlock];
+    const uint32_t bid = blockIdx.x;
     uint32_t w = 0;
     while (w + 1 < (uint32_t)tab.W && tab.rboff[w + 1] <= bid) w++;   // uniform scan, W <= 256
-    const uint32_t bx = bid - tab.rboff[w], m = tab.mw[w];
-    uint32_t B = tab.boff[w + 1] - tab.boff[w];
-    uint32_t t = bx * kBlock + threadIdx.x;
-    uint32_t T = (B + m - 1) / m;
-    XyzzLazy<C> mine = xyzz_lazy_inf<C>();
+    const uint32_t bx = bid - tab.rboff[w], lgm = tab.lgm[w], m = 1u << lgm;
+    const uint32_t B = tab.boff[w + 1] - tab.boff[w];
+    const uint32_t T = B >> lgm;                                       // threads of the window: a power of two
+    const uint32_t t = bx * kBlock + threadIdx.x;
+    const int live = T < (uint32_t)kBlock ? (int)T : kBlock;
+    XyzzLazy<C> run = xyzz_lazy_inf<C>(), tri = xyzz_lazy_inf<C>();
     if (t < T) {
-        XyzzLazy<C> run = xyzz_lazy_inf<C>(), tri = xyzz_lazy_inf<C>();
-        uint32_t lo = t * m, hi = lo + m < B ? lo + m : B;
-        for (uint32_t j = hi; j-- > lo;) {
-            uint32_t g = tab.boff[w] + j;
-            uint32_t nt = ntasks[g];
+        const uint32_t lo = t * m;
+        for (uint32_t j = lo + m; j-- > lo;) {
+            const uint32_t g = tab.boff[w] + j;
+            const uint32_t nt = ntasks[g];
             if (nt) {
                 // a bucket cut into 2..kLightMax tasks is summed here (a separate lane-per-bucket kernel for it cost 0.1-0.2 ms
                 // at n = 2^16); a heavier bucket was already folded into its first record by k_combine_chunks / _heavy
-                uint32_t t0 = task_off[g], lim = nt <= kLightMax ? nt : 1;
+                const uint32_t t0 = task_off[g], lim = nt <= kLightMax ? nt : 1;
                 for (uint32_t k = 0; k < lim; k++) run = xyzz_lazy_add(run, xyzz_lazy_unpack(tsum[t0 + k]));
             }
             tri = xyzz_lazy_add(tri, run);
         }
-        mine = xyzz_lazy_add(tri, xyzz_mul_small<C>(lo, run));
     }
-    uint32_t live = T - bx * kBlock;
-    mine = block_tree_sum<C>(mine, lds, live < (uint32_t)kBlock ? (int)live : kBlock);
-    if (threadIdx.x == 0) partial[bid] = xyzz_lazy_pack(mine);
+    if ((int)threadIdx.x < live) {
+        lds[threadIdx.x] = xyzz_lazy_pack(run);
+        lds[kBlock + threadIdx.x] = xyzz_lazy_pack(tri);
+    }
+    __syncthreads();
+    plane_tree<C>(lds, live, kBlock, 1);
+    int lg = 0;
+    while ((1 << lg) < live) lg++;
+    if ((int)threadIdx.x < 2 + lg) {
+        const int k = (int)threadIdx.x;
+        partial[(size_t)bid * kPartPerBlock + k] = k == 0 ? lds[kBlock] : k == 1 ? lds[0] : lds[1 << (k - 2)];
+    }
 }
 
-// grid = windows of the group: window_sum[w] = sum of partial[rboff[w] .. rboff[w+1])
-template <class C>
-__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, WinTab tab, XyzzPacked<C>* __restrict__ window_sum, int w0) {
+// Second level, grid = (windows, kPartPerBlock): block (w, a) folds ONE kind of partial over the nblk = rboff[w+1] - rboff[w]
+// blocks of window w (nblk is a power of two) into the window's tail records  [tri | thread-bit planes | block-bit planes]:
+//   a = 0              sum of the blocks' tri                               -> record 0
+//   a = 2 + k          sum of the blocks' planes of thread bit k            -> record 1 + k
+//   a = 1              the blocks' run totals: their planes over the BLOCK index (bits log2(256).. of the thread index)
+//                                                                           -> records 1 + lgT .. (the total itself is not a record)
+// HOSTREC: records leave in the host's form (xyzz_lazy_to_host_record) -- the normal case; false keeps them as lazy XYZZ for the
+// device-side tail (k_tail_fold).
+template <class C, bool HOSTREC>
+__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, WinTab tab, XyzzPacked<C>* __restrict__ window_sum) {
     __shared__ XyzzPacked<C> lds[kBlock];
-    uint32_t w = (uint32_t)w0 + blockIdx.x;
-    const uint32_t first = tab.rboff[w], per_window = tab.rboff[w + 1] - first;
-    XyzzLazy<C> mine = xyzz_lazy_inf<C>();
-    for (uint32_t j = threadIdx.x; j < per_window; j += kBlock) mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(partial[first + j]));
-    mine = block_tree_sum<C>(mine, lds, per_window < (uint32_t)kBlock ? (int)per_window : kBlock);
-    if (threadIdx.x == 0) window_sum[w] = xyzz_lazy_pack(mine);
+    const uint32_t w = blockIdx.x, a = blockIdx.y;
+    const uint32_t first = tab.rboff[w], nblk = tab.rboff[w + 1] - first;
+    const uint32_t B = tab.boff[w + 1] - tab.boff[w], T = B >> tab.lgm[w];
+    const uint32_t live = T < (uint32_t)kBlock ? T : (uint32_t)kBlock;
+    int lgT = 0, lgB = 0;
+    while ((1u << lgT) < live) lgT++;
+    while ((1u << lgB) < nblk) lgB++;
+    if (a >= 2u + (uint32_t)lgT) return;                      // this window has fewer thread-bit planes
+    XyzzPacked<C>* rec = window_sum + tab.roff[w];
+    if (a == 1 && lgB == 0) return;                           // one block: its run total is not needed
+    if (threadIdx.x < nblk) lds[threadIdx.x] = partial[(size_t)(first + threadIdx.x) * kPartPerBlock + a];
+    __syncthreads();
+    plane_tree<C>(lds, (int)nblk, kBlock, 0, a == 1);         // sum at lds[0]; for a = 1 the block-bit planes at lds[1 << k]
+    if (a == 1) {
+        if ((int)threadIdx.x < lgB) {
+            const XyzzPacked<C> v = lds[1u << threadIdx.x];
+            rec[1 + lgT + threadIdx.x] = HOSTREC ? xyzz_lazy_to_host_record(xyzz_lazy_unpack(v)) : v;
+        }
+    } else if (threadIdx.x == 0) {
+        const XyzzPacked<C> v = lds[0];
+        rec[a == 0 ? 0 : a - 1] = HOSTREC ? xyzz_lazy_to_host_record(xyzz_lazy_unpack(v)) : v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- small MSM (n <= kSmallMsmMax)
@@ -586,7 +648,7 @@ __device__ __forceinline__ uint32_t window_bits(const uint64_t (&q)[4], int off,
     return (uint32_t)v & ((1u << cw) - 1);
 }
 
-template <class C>
+template <class C, bool HOSTREC>
 __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __restrict__ pts, const ScalarWords* __restrict__ sc1,
                                                       const ScalarWords* __restrict__ sc2, uint32_t n, WinTab tab,
                                                       XyzzPacked<C>* __restrict__ window_sum) {
@@ -610,7 +672,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         mine = xyzz_lazy_add(mine, acc);
     }
     mine = block_tree_sum<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
-    if (threadIdx.x == 0) window_sum[w] = xyzz_lazy_pack(mine);
+    if (threadIdx.x == 0) window_sum[tab.roff[w]] = HOSTREC ? xyzz_lazy_to_host_record(mine) : xyzz_lazy_pack(mine);
 }
 
 // ---------------------------------------------------------------------------------------------- device tail (optional)
@@ -618,15 +680,18 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
 // result can stay in HBM and to put a number on the design decision: ~2 ms here against ~0.13 ms for
 // the host fold (bp_host_tail.hpp).  out_le = canonical x || y little-endian words (all-zero = identity).
 template <class C>
-__global__ void __launch_bounds__(64) k_tail_fold(const XyzzPacked<C>* __restrict__ wsum, WinTab tab, int w_begin, int w_end, uint32_t* __restrict__ out_le) {
+__global__ void __launch_bounds__(64) k_tail_fold(const XyzzPacked<C>* __restrict__ rec, const uint16_t* __restrict__ pos, int nrec, uint32_t* __restrict__ out_le) {
     using Fp = typename C::Fp;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int top = 0;
+    for (int r = 0; r < nrec; r++) top = pos[r] > top ? pos[r] : top;
     XyzzLazy<C> acc = xyzz_lazy_inf<C>();
 #pragma unroll 1
-    for (int w = w_end - 1; w >= w_begin; w--) {
+    for (int p = top; p >= 0; p--) {          // Horner over the bit positions: one doubling per position, the records of weight 2^p added on the way
+        if (p < top) acc = xyzz_lazy_dbl(acc);
 #pragma unroll 1
-        for (int i = 0; i < tab.cw[w]; i++) acc = xyzz_lazy_dbl(acc);
-        acc = xyzz_lazy_add(acc, xyzz_lazy_unpack(wsum[w]));
+        for (int r = 0; r < nrec; r++)
+            if (pos[r] == p) acc = xyzz_lazy_add(acc, xyzz_lazy_unpack(rec[r]));
     }
     Aff<C> a = xyzz_to_aff<C>(xyzz_lazy_to_strict(acc));
     uint32_t xw[Fp::NW], yw[Fp::NW];
@@ -678,6 +743,55 @@ __global__ void __launch_bounds__(kBlock) k_points_from_resident(const AffPacked
     fe_pack_words<Fp>(yw, fe_from_mont<Fp>(a.y));
     uint32_t* p = raw + i * 2 * Fp::NW;
     for (int k = 0; k < Fp::NW; k++) { p[k] = xw[k]; p[Fp::NW + k] = yw[k]; }
+}
+
+// ---------------------------------------------------------------------------------------------- window-multiples table
+// rows[w * n + i] = 2^(c w) P_i  for w < W1 (row 0 = the vector itself): the table behind the merged-window MSM (WinTab::merged).
+// The generators of a proof system are public parameters reused by every proof (/root/reference src/r1cs/prover.rs:347-362,
+// src/ipp.rs:91,104,158,170), so the table is built once per vector (bp_g1vec_precompute).
+// One lane per point: c doublings per window in the lazy domain, every window's XYZZ value and the running product of its
+// ZZ * ZZZ parked in HBM (tmp / pre), ONE field inversion per lane, then the walk back (Montgomery's trick) turns each parked
+// value into an affine row with 6 products.  An identity point gives identity rows.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_table_build(const AffPacked<C>* __restrict__ pts, size_t n, int c, int W1, XyzzPacked<C>* __restrict__ tmp,
+                                                        FePacked<typename C::Fp>* __restrict__ pre, AffPacked<C>* __restrict__ rows) {
+    using Fp = typename C::Fp;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffPacked<C> p0 = pts[i];
+    rows[i] = p0;
+    const Aff<C> p = aff_unpack(p0);
+    if (aff_is_inf(p)) {
+        AffPacked<C> z;
+        for (int k = 0; k < Fp::NW; k++) { z.x.w[k] = 0; z.y.w[k] = 0; }
+        for (int w = 1; w < W1; w++) rows[(size_t)w * n + i] = z;
+        return;
+    }
+    XyzzLazy<C> acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
+    FeB<Fp, 2> prod = feb_widen<2>(feb_from_strict<Fp>(fe_one<Fp>()));
+#pragma unroll 1
+    for (int w = 1; w < W1; w++) {
+#pragma unroll 1
+        for (int k = 0; k < c; k++) acc = xyzz_lazy_dbl(acc);
+        tmp[(size_t)(w - 1) * n + i] = xyzz_lazy_pack(acc);
+        prod = feb_mul(prod, feb_mul(acc.zz, acc.zzz));
+        Fe<Fp> pv;
+        for (int k = 0; k < Fp::NL; k++) pv.v[k] = prod.v[k];
+        pre[(size_t)(w - 1) * n + i] = fe_pack(pv);                       // < 2p: fits the packed words
+    }
+    FeB<Fp, 2> inv = feb_widen<2>(feb_from_strict<Fp>(fe_inv<Fp>(feb_to_strict(prod))));
+#pragma unroll 1
+    for (int w = W1 - 1; w >= 1; w--) {
+        const XyzzLazy<C> q = xyzz_lazy_unpack(tmp[(size_t)(w - 1) * n + i]);
+        FeB<Fp, 2> prev = feb_widen<2>(feb_from_strict<Fp>(fe_one<Fp>()));
+        if (w > 1) { const Fe<Fp> pv = fe_unpack(pre[(size_t)(w - 2) * n + i]); for (int k = 0; k < Fp::NL; k++) prev.v[k] = pv.v[k]; }
+        const FeB<Fp, 2> tinv = feb_mul(inv, prev);                       // 1 / (ZZ_w ZZZ_w)
+        inv = feb_mul(inv, feb_mul(q.zz, q.zzz));
+        Aff<C> a;
+        a.x = feb_to_strict(feb_mul(q.x, feb_mul(tinv, q.zzz)));          // X / ZZ
+        a.y = feb_to_strict(feb_mul(q.y, feb_mul(tinv, q.zz)));           // Y / ZZZ
+        rows[(size_t)w * n + i] = aff_pack(a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- batched scalar mul

@@ -79,6 +79,15 @@ int bp_ctx_synchronize(bp_ctx* ctx);
 int bp_ctx_set_device_tail(bp_ctx* ctx, int on);
 /* Pippenger window width in bits (2..16) for subsequent MSMs; 0 = choose from n (default). */
 int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
+/* Engineering knobs of the MSM pipeline, per context, VALIDATED when set (BP_ERR_ARG otherwise).  Until round 2 these were
+ * environment variables trusted as they were (a tile that is not a multiple of 256 silently dropped scalars); since round 3 the
+ * library reads no environment variable that can change a result (BP_VERBOSE / BP_TRACE only add diagnostics on stderr).
+ * value 0 = automatic (the default).  Sibling contexts (R1CS commitments in flight) and bp_msm_g1_multi shards inherit them. */
+#define BP_TUNE_TILE 1        /* scalars per block of the binning passes: a multiple of 256 in [256, 16384] */
+#define BP_TUNE_REDUCE_M 2    /* buckets per bucket-reduce thread: a power of two in [1, 16384] */
+#define BP_TUNE_TASK_TARGET 3 /* number of tasks the accumulate kernel aims at: [1024, 2^28] */
+#define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 512 terms */
+int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
 /* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
  * of a small proof; blocks are recycled in stream order).  bp_ctx_trim returns the cached blocks to the driver. */
 int bp_ctx_trim(bp_ctx* ctx);
@@ -95,10 +104,26 @@ int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, i
 int bp_g1vec_free(bp_g1vec* v);
 size_t bp_g1vec_len(const bp_g1vec* v);
 /* Raw HBM pointer and byte stride of the resident vector (2*fp_bytes per point), for callers that manage device
- * memory themselves (torch tensors, RCCL buffers). */
+ * memory themselves (torch tensors, RCCL buffers).
+ * LIFETIME: the library orders every use of a vector on its owner's stream and recycles freed blocks through the context's pool
+ * without synchronising.  A pointer obtained here leaves that order (a torch / RCCL stream, a bp_g1vec_wrap_device view on
+ * ANOTHER context), so from this call on bp_g1vec_free of the owner waits for the whole device before the block can be reused
+ * (the behaviour of hipFree).  A view must still not be used after its owner has been freed. */
 void* bp_g1vec_device_ptr(bp_g1vec* v);
 /* Non-owning view over caller-owned HBM already in the resident layout (as produced by bp_g1vec_device_ptr). */
 int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out);
+/* Window-multiples table of a resident vector, OPT-IN (round 3): rows 2^(c w) P_i for every window w are built once
+ * (one launch: c doublings per window per point, one inversion per point) and kept with the vector until it is freed or
+ * bp_g1vec_drop_table.  From then on every MSM over the WHOLE vector (bp_msm_g1, _begin, _pair, and the IPP / R1CS calls that
+ * take it as G or H) sorts on the bucket alone: all windows of a scalar share one set of 2^(c-1) buckets, the bucket reduce
+ * runs over one window instead of ~16 and the host tail shrinks from ~255 doublings to c.  For the generators of a proof
+ * system -- public parameters reused by every proof (/root/reference src/r1cs/prover.rs:347-362, src/ipp.rs:91,104,158,170).
+ * Results are bit-identical with and without a table.  window_bits: 2..16, 0 = chosen from n; memory = ceil((fr_bits+1)/c) x the
+ * vector.  The caller must not modify the vector's points afterwards (bp_g1vec_device_ptr writers): the table would be stale. */
+int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits);
+int bp_g1vec_drop_table(bp_g1vec* v);
+/* window width, number of windows and bytes of the vector's table (all 0 when it has none) */
+int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_t* bytes);
 /* out[i] = k[i] * G.  Batched form of `&G1::generator() * &FieldElement` (src/utils/mod.rs:34); used to build
  * synthetic generator vectors on the device. */
 int bp_g1vec_fixed_base_mul(bp_ctx* ctx, const bp_frvec* k, bp_g1vec** out);

@@ -28,6 +28,10 @@ def main():
     ctx.enable_timing(not notime)
     if os.environ.get("BP_DEVICE_TAIL"):
         ctx.set_device_tail(True)
+    # sweep knobs of THIS script (the library itself reads no tuning variable): TM_TILE / TM_REDUCE_M / TM_TASK_TARGET / TM_SMALL_MSM
+    for var, knob in (("TM_TILE", bp.TUNE_TILE), ("TM_REDUCE_M", bp.TUNE_REDUCE_M), ("TM_TASK_TARGET", bp.TUNE_TASK_TARGET), ("TM_SMALL_MSM", bp.TUNE_SMALL_MSM)):
+        if os.environ.get(var):
+            ctx.set_tuning(knob, int(os.environ[var]))
     for lg in lgs:
         n = 1 << lg
         kv = bp.FieldElementVector.from_bytes(ctx, rand_scalars(ctx, n, 1), n)

@@ -335,11 +335,10 @@ def test_short_differential_fuzz():
 
 
 def test_one_bucket_holds_everything():
-    """All scalars equal to 1 at n = 2^20 with the task length forced down to 8 (BP_TASK_TARGET): ONE bucket with 131072 task
+    """All scalars equal to 1 at n = 2^20 with the task length forced down to 8 (bp_ctx_set_tuning, BP_TUNE_TASK_TARGET): ONE bucket with 131072 task
     sums = 512 chunks, i.e. the strided second stage of the heavy-bucket combine (> 256 chunk sums per bucket).  The script
     checks sum_i (k_i G) == (sum_i k_i) G on both curves, for the default and a narrow window width."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BP_TASK_TARGET=str(1 << 26))
-    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_huge_bucket.py")], capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_huge_bucket.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.count(" ok") == 4 and "MISMATCH" not in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
