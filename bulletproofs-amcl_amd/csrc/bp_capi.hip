@@ -37,8 +37,27 @@ static int geom_reduce(MsmGeom& g, WinTab& t, const bp_tuning* tn) {
         }
         return blocks;
     };
+    // ... and among those the one with the shortest dependent chain of k_bucket_reduce for the widest window:
+    //   2m (running sums) + log2(threads per block) (block tree) + passes * log2(blocks per window) (window level, last block;
+    //   its LDS holds kReduceSlots / blocks partial kinds per pass)
+    // m = 1 is not always best: a merged (table) MSM at c = 16 has 128 blocks per scalar set and would fold its 10 partial kinds
+    // in three passes of 7 steps; m = 4 gives 8 + 8 + 5.
+    auto chain = [&](uint32_t m) {
+        uint32_t worst = 0;
+        for (int w = 0; w < W; w++) {
+            const uint32_t B = t.boff[w + 1] - t.boff[w], mw = m < B ? m : B, T = B / mw, nblk = (T + kBlock - 1) / kBlock;
+            const uint32_t lgT = (uint32_t)ilog2(T < (uint32_t)kBlock ? T : (uint32_t)kBlock), lgB = (uint32_t)ilog2(nblk), kinds = 2 + lgT;
+            uint32_t per = (uint32_t)kReduceSlots / nblk;
+            if (per > kinds) per = kinds;
+            const uint32_t passes = nblk > 1 ? (kinds + per - 1) / per : 0;
+            const uint32_t steps = 2 * mw + lgT + passes * lgB;
+            if (steps > worst) worst = steps;
+        }
+        return worst;
+    };
     uint32_t m = 1;
     while (m < (1u << 15) && blocks_for(m) > 256) m <<= 1;
+    for (uint32_t m2 = m << 1; m2 <= 64; m2 <<= 1) if (chain(m2) < chain(m)) m = m2;
     if (tn && tn->reduce_m) m = tn->reduce_m;
     g.m = m;
     uint32_t rb = 0, nrec = 0;
@@ -209,9 +228,8 @@ struct Impl {
     }
 
     // Device stage: tail records of  sum_i s_i P_i  into ctx->window_sum (g.nrec records).
-    // host_rec: records in the host's form (the fold of bp_host_tail.hpp); false: lazy XYZZ for the device-side tail (k_tail_fold)
     static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g, const ScalarWords* sc2 = nullptr,
-                           size_t nnz = 0, bool host_rec = true, const bp_g1table* tb = nullptr) {
+                           size_t nnz = 0, const bp_g1table* tb = nullptr) {
         // tb: window-multiples table of `pts` (same n): the merged-window pipeline over its rows
         int rc = tb ? msm_geom_table(g, C::Fr::BITS, tb->c, tb->W, sc2 ? 2 : 1, &ctx->tuning)
                     : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning);
@@ -229,8 +247,7 @@ struct Impl {
         if ((rc = ctx->window_sum.reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         if (g.small) {   // one launch: block per window, lane per term (k_small_msm)
             if (tm) for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st));
-            if (!host_rec) hipLaunchKernelGGL((k_small_msm<C, false>), dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
-            else hipLaunchKernelGGL((k_small_msm<C, true>), dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
+            hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
             if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
             HIPCHK(hipGetLastError());
@@ -242,6 +259,9 @@ struct Impl {
         const uint64_t kTaskTarget = ctx->tuning.task_target ? ctx->tuning.task_target : 2 * 131072;
         const uint64_t entries = (uint64_t)W * (nnz ? nnz : n);
         uint32_t L = 8;
+        // (Round 3 tried "plentiful" from a quarter of the target on, so that the 2^16 merged buckets of a table MSM stay one task each
+        // and the reduce chain loses the recombination: reduce 0.48 -> 0.34 ms, but the accumulate then lasts as long as its LONGEST
+        // bucket -- one task per lane, nothing to balance -- 0.31 -> 0.51 ms.  Kept as it was.)
         if (nb >= kTaskTarget) { while ((uint64_t)L * nb < 2 * entries && L < (1u << 20)) L <<= 1; if (L < 128) L = 128; }
         else { while ((uint64_t)L * kTaskTarget < entries && L < (1u << 20)) L <<= 1; }
         uint32_t lshift = 0;
@@ -265,7 +285,7 @@ struct Impl {
         if ((rc = ctx->tsum.reserve(ctx, max_tasks * kXyzzBytes))) return rc;
         if ((rc = ctx->heavy.reserve(ctx, max_heavy * 4))) return rc;
         if ((rc = ctx->heavy_chunks.reserve(ctx, max_chunks * sizeof(uint2)))) return rc;
-        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16;
+        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16 + kMaxWindows;      // + one "blocks done" counter per window (k_bucket_reduce)
         if ((rc = ctx->meta.reserve(ctx, kMetaWords * 4))) return rc;
         if ((rc = ctx->partial.reserve(ctx, (size_t)tabR.rboff[WR] * kPartPerBlock * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // bucket starts
@@ -299,6 +319,7 @@ struct Impl {
         uint32_t* total_tasks = bins + kTaskBins;
         uint32_t* nheavy = bins + kTaskBins + 1;
         uint32_t* nchunks = bins + kTaskBins + 2;
+        uint32_t* win_done = bins + ((kTaskBins + 3 + 15) / 16) * 16;
         uint32_t* order = (uint32_t*)ctx->order.p;
         uint32_t* t_start = (uint32_t*)ctx->t_start.p;
         uint32_t* t_len = (uint32_t*)ctx->t_len.p;
@@ -336,11 +357,8 @@ struct Impl {
         hipLaunchKernelGGL(k_combine_chunks<C>, dim3((unsigned)(max_chunks < 256 ? max_chunks : 256)), dim3(kBlock), 0, st, chunks, nchunks, task_off, ntasks, tsum);
         hipLaunchKernelGGL(k_combine_heavy<C>, dim3((unsigned)(max_heavy < 256 ? max_heavy : 256)), dim3(kBlock), 0, st, heavy, nheavy, task_off, ntasks, tsum);
         BP_TRACE_SYNC(ctx, "k_combine_heavy<C>");
-        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tabR.rboff[WR]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tabR, partial);
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(tabR.rboff[WR]), dim3(kBlock), 0, st, tsum, task_off, ntasks, tabR, partial, win_done, wsum);
         BP_TRACE_SYNC(ctx, "k_bucket_reduce<C>");
-        if (!host_rec) hipLaunchKernelGGL((k_window_sums<C, false>), dim3(WR, kPartPerBlock), dim3(kBlock), 0, st, partial, tabR, wsum);
-        else hipLaunchKernelGGL((k_window_sums<C, true>), dim3(WR, kPartPerBlock), dim3(kBlock), 0, st, partial, tabR, wsum);
-        BP_TRACE_SYNC(ctx, "k_window_sums<C>");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
         HIPCHK(hipGetLastError());
         return BP_OK;
@@ -395,7 +413,7 @@ struct Impl {
     static int msm(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, uint8_t* out_le, const bp_g1table* tb = nullptr) {
         if (n == 0) { memset(out_le, 0, 2 * 4 * Fp::NW); ctx->last_ms_n = 0; return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g, nullptr, 0, !ctx->device_tail, tb);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g, nullptr, 0, tb);
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         if (ctx->device_tail) {   // all-device variant: one lane folds the records (see k_tail_fold)
@@ -425,7 +443,7 @@ struct Impl {
         ctx->pending_n = n;
         if (n == 0) { ctx->pending = true; return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g, nullptr, 0, true, tb);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g, nullptr, 0, tb);
         if (rc) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -448,7 +466,7 @@ struct Impl {
     static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le, size_t nnz = 0, const bp_g1table* tb = nullptr) {
         if (n == 0) { memset(out1_le, 0, 2 * 4 * Fp::NW); memset(out2_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
         MsmGeom g;
-        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz, true, tb);
+        int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz, tb);
         if (rc) return rc;
         const int R1 = g.nrec / 2;                      // records of one scalar set
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
@@ -530,12 +548,15 @@ struct Impl {
         return BP_OK;
     }
 
-    // one affine point (canonical LE) -> a tail record in the host's form (bp_host_tail.hpp)
+    // one affine point (canonical LE) -> a packed XYZZ record in the device's Montgomery radix (host arithmetic)
     static void record_from_affine(const uint8_t* le, XyzzPacked<C>* out) {
         uint32_t xw[Fp::NW], yw[Fp::NW];
         memcpy(xw, le, 4 * Fp::NW);
         memcpy(yw, le + 4 * Fp::NW, 4 * Fp::NW);
-        tail().record_from_affine(xw, yw, out);
+        Aff<C> a;
+        a.x = fe_to_mont<Fp>(fe_unpack_words<Fp>(xw));
+        a.y = fe_to_mont<Fp>(fe_unpack_words<Fp>(yw));
+        *out = xyzz_pack(xyzz_from_aff(a));
     }
 
     static int msm_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
@@ -677,6 +698,55 @@ int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp
         hipLaunchKernelGGL(k_table_build<Bn254>, grid, dim3(kBlock), 0, ctx->stream, (const AffPacked<Bn254>*)points, n, c, W1, (XyzzPacked<Bn254>*)tmp.p,
                            (FePacked<Bn254Fp>*)pre.p, (AffPacked<Bn254>*)t->d);
     if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    *out = t;
+    return BP_OK;
+}
+
+// Table of the concatenation [G[offG .. offG+n) | H[offH .. offH+n) | extra] from the tables of G and H (device copies, row by row)
+// and the window multiples of the one extra point (host arithmetic, ~0.1 ms) -- the vectors the prover's MSMs run over
+// ([G | H | Q] of an inner-product argument, [G | H | B_blinding] of the R1CS commitments).  *out stays NULL (BP_OK) when G or H has
+// no table, or their widths differ: the caller then runs the plain pipeline.
+int bp_internal_table_concat(bp_ctx* ctx, const bp_g1vec* G, size_t offG, const bp_g1vec* H, size_t offH, size_t n, const uint8_t* extra_le, bp_g1table** out) {
+    *out = nullptr;
+    if (offG > G->n || n > G->n - offG || offH > H->n || n > H->n - offH) return BP_ERR_LENGTH;
+    const bp_g1table *tg = G->table ? G->table : G->tview, *th = H->table ? H->table : H->tview;
+    if (!G->table) offG += G->tview_off;
+    if (!H->table) offH += H->tview_off;
+    if (!tg || !th || tg->c != th->c || tg->W != th->W || offG + n > tg->n || offH + n > th->n) return BP_OK;
+    const size_t m = 2 * n + 1;
+    const int W1 = tg->W, c = tg->c;
+    if ((uint64_t)W1 * m >= ((uint64_t)1 << 31)) return BP_OK;
+    const size_t pt = 2 * (size_t)fp_bytes_of(ctx->curve);
+    bp_g1table* t = new (std::nothrow) bp_g1table();
+    if (!t) return BP_ERR_DEVICE;
+    t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = c; t->W = W1;
+    t->d = ctx->pool->get((size_t)W1 * m * pt, &t->cap);
+    PoolBlock raw, conv;
+    if (!t->d || !raw.alloc(ctx, (size_t)W1 * pt) || !conv.alloc(ctx, (size_t)W1 * pt)) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    int rc = host_pinned_reserve(ctx, (size_t)W1 * pt);
+    if (rc) { bp_internal_table_free(t); return rc; }
+    hipStream_t s = ctx->stream;
+    // the pinned staging buffer may still be the source / target of an earlier copy on this stream
+    if (hipStreamSynchronize(s) != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    if (ctx->curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().window_multiples(extra_le, c, W1, (uint8_t*)ctx->host_pinned);
+    else Impl<Bn254>::tail().window_multiples(extra_le, c, W1, (uint8_t*)ctx->host_pinned);
+    bool ok = hipMemcpyAsync(raw.p, ctx->host_pinned, (size_t)W1 * pt, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        if (ctx->curve == BP_CURVE_BLS12_381)
+            hipLaunchKernelGGL(k_points_to_resident<Bls381>, dim3((unsigned)((W1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, (const uint32_t*)raw.p, (size_t)W1, (AffPacked<Bls381>*)conv.p, (uint32_t*)nullptr);
+        else
+            hipLaunchKernelGGL(k_points_to_resident<Bn254>, dim3((unsigned)((W1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, (const uint32_t*)raw.p, (size_t)W1, (AffPacked<Bn254>*)conv.p, (uint32_t*)nullptr);
+        ok = hipGetLastError() == hipSuccess;
+    }
+    uint8_t* dst = (uint8_t*)t->d;
+    if (ok && n) {
+        ok = hipMemcpy2DAsync(dst, m * pt, (const uint8_t*)tg->d + offG * pt, tg->n * pt, n * pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipMemcpy2DAsync(dst + n * pt, m * pt, (const uint8_t*)th->d + offH * pt, th->n * pt, n * pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    }
+    ok = ok && hipMemcpy2DAsync(dst + 2 * n * pt, m * pt, conv.p, pt, pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    // the multiples live in the pinned buffer until the H2D copy has run: wait (this path runs once per proof, not per round)
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     *out = t;
     return BP_OK;
 }

@@ -30,6 +30,7 @@ struct bp_ipp_state {
     // default mode (generators never folded, see bp_ipp.cuh): resident [G | H | Q], coefficient vectors, L/R scalars
     bool fold_generators;
     void *Pall, *cG, *cH, *sL, *sR;
+    bp_g1table* table;       // window multiples of [G | H | Q] when G and H carry tables (bp_g1vec_precompute): every round's MSM is merged-window
     int device;
     // every buffer above is a block of the context's pool (recycled, no hipMalloc / hipFree per proof)
     DevPool* pool;
@@ -135,7 +136,7 @@ struct Ipp {
                                (const ScalarWords*)st->cH, cLR, st->n0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
-            return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1);   // both sums in one pipeline pass
+            return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1, st->table);   // both sums in one pipeline pass
         }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
                            (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,
@@ -787,6 +788,7 @@ int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le,
 // ---- IPP device-resident state ------------------------------------------------------------------------------
 int bp_ipp_state_free(bp_ipp_state* st) {
     if (!st) return BP_OK;
+    if (st->table) bp_internal_table_free(st->table);
     if (st->blocks) {
         for (auto& b : *st->blocks) st->pool->put(b.first, b.second);
         delete st->blocks;
@@ -853,6 +855,10 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { bp_ipp_state_free(st); return BP_ERR_DEVICE; }
+    if (!st->fold_generators && 2 * n + 1 > kSmallMsmMax) {     // smaller rounds run as ONE launch (k_small_msm): nothing for a table to merge
+        rc = bp_internal_table_concat(ctx, G, 0, H, 0, n, Q_le, &st->table);
+        if (rc) { bp_ipp_state_free(st); return rc; }
+    }
     *out = st;
     return BP_OK;
 }

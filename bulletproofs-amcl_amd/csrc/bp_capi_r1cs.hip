@@ -79,6 +79,7 @@ struct R1cs {
             HIPCHK(hipMemcpyAsync((uint8_t*)v->d + n * row, (const uint8_t*)H->d + off * row, n * row, hipMemcpyDeviceToDevice, s));
         }
         HIPCHK(hipMemcpyAsync((uint8_t*)v->d + 2 * n * row, hv->d, row, hipMemcpyDeviceToDevice, s));
+        if (2 * n + 1 > kSmallMsmMax) RC(bp_internal_table_concat(ctx, G, off, H, off, n, h_le, &v->table));   // G, H precomputed: merged-window MSMs (freed with v)
         *out = v;
         return BP_OK;
     }
@@ -275,6 +276,8 @@ struct R1cs {
         T.keep(Gp);
         RC(bp_g1vec_wrap_device(ctx, H->d, pn, &Hp));
         T.keep(Hp);
+        Gp->tview = G->table ? G->table : G->tview; Gp->tview_off = G->table ? 0 : G->tview_off;      // precomputed generators: the IPP's rounds inherit their tables
+        Hp->tview = H->table ? H->table : H->tview; Hp->tview_off = H->table ? 0 : H->tview_off;
         size_t lg_out = 0;
         RC(bp_ipp_create(ctx, t, Q, ippin[2], ippin[3], Gp, Hp, ippin[0], ippin[1], Lp, Rp, &lg_out, ab, ab + 32));   // :567-576
         return lg_out == lg ? BP_OK : BP_ERR_DEVICE;

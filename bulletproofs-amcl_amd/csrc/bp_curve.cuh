@@ -427,27 +427,6 @@ template <class C> BP_HD XyzzPacked<C> xyzz_lazy_pack(const XyzzLazy<C>& p) {
     return r;
 }
 
-// Tail record for the host (bp_host_tail.hpp): the point as JACOBIAN coordinates with Z = ZZZ (then Z^2 = ZZ^3, Z^3 = ZZZ^3, so
-// X_J = x Z^2 = X ZZ^2 and Y_J = y Z^3 = Y ZZZ^2), every coordinate canonical and in the host's Montgomery radix, stored in the x,
-// y, zz slots of a packed record (zzz = 0); the identity is all-zero.  Seven products on one lane per record: it moves the
-// per-record conversion (eight host products in rounds 1-2) to where records are produced in parallel.
-template <class C, class M = MulInline> BP_HD XyzzPacked<C> xyzz_lazy_to_host_record(const XyzzLazy<C>& p) {
-    using Fp = typename C::Fp;
-    XyzzPacked<C> r;
-    for (int i = 0; i < Fp::NW; i++) { r.x.w[i] = 0; r.y.w[i] = 0; r.zz.w[i] = 0; r.zzz.w[i] = 0; }
-    if (p.inf) return r;
-    FeB<Fp, 1> k;
-    for (int i = 0; i < Fp::NL; i++) k.v[i] = HostRadix<Fp>::H.rh[i];
-    FeB<Fp, 2> zz2 = M::sqr(p.zz), zzz2 = M::sqr(p.zzz);
-    FeB<Fp, 2> xj = M::mul(p.x, zz2);            // 8 * 2
-    FeB<Fp, 2> yj = M::mul(p.y, zzz2);           // 4 * 2
-    Fe<Fp> x = feb_to_strict(M::mul(xj, k)), y = feb_to_strict(M::mul(yj, k)), z = feb_to_strict(M::mul(p.zzz, k));
-    fe_pack_words<Fp>(r.x.w, x);
-    fe_pack_words<Fp>(r.y.w, y);
-    fe_pack_words<Fp>(r.zz.w, z);
-    return r;
-}
-
 template <class C> BP_HD XyzzLazy<C> xyzz_lazy_unpack(const XyzzPacked<C>& p) {
     using Fp = typename C::Fp;
     XyzzLazy<C> r;

@@ -637,27 +637,6 @@ template <class P> BP_HD FeB<P, 2> feb_neg_canonical(const Fe<P>& a) {
     return r;
 }
 
-// 2^(64 ceil(NW / 2)) mod p as a PLAIN integer in 30-bit limbs: the Montgomery radix of the host tail (bp_host_tail.hpp).  A device
-// residue x R_dev multiplied (Montgomery) by this constant is x R_host, i.e. the same element in the host's representation.
-template <class P>
-struct HostRadixConsts { uint32_t rh[P::NL]; };
-template <class P>
-constexpr HostRadixConsts<P> make_host_radix() {
-    HostRadixConsts<P> c{};
-    uint32_t t[P::NL] = {};
-    t[0] = 1;
-    for (int k = 0; k < 64 * ((P::NW + 1) / 2); k++) {
-        uint32_t carry = 0;
-        for (int i = 0; i < P::NL; i++) { uint32_t v = (t[i] << 1) | carry; carry = v >> LB; t[i] = v & LMASK; }
-        bool ge = true;
-        for (int i = P::NL - 1; i >= 0; i--) { if (t[i] != P::C.mod[i]) { ge = t[i] > P::C.mod[i]; break; } }
-        if (ge) { uint32_t br = 0; for (int i = 0; i < P::NL; i++) { uint32_t v = t[i] - P::C.mod[i] - br; br = v >> 31; t[i] = v & LMASK; } }
-    }
-    for (int i = 0; i < P::NL; i++) c.rh[i] = t[i];
-    return c;
-}
-template <class P> struct HostRadix { static constexpr HostRadixConsts<P> H = make_host_radix<P>(); };
-
 // x < B p  ->  canonical [0, p): conditional subtraction of 2^j p, j descending
 template <class P, int B> BP_HD Fe<P> feb_to_strict(const FeB<P, B>& a) {
     Fe<P> r;

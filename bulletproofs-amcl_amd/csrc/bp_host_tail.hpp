@@ -7,8 +7,8 @@
 // Round 3: the bucket reduce hands over one record per BIT PLANE of the reduce-thread index (bp_kernels.cuh:
 // k_bucket_reduce) instead of multiplying by the weights on the device, so a 2^20-point MSM arrives as ~200 records instead of 16.
 // The fold therefore had to become cheap per record:
-//   * records arrive in HOST form (bp_curve.cuh: xyzz_lazy_to_host_record): Jacobian (X ZZ^2, Y ZZZ^2, ZZZ), canonical, already
-//     in this file's Montgomery radix 2^(64 N) -- loading one is a copy (rounds 1-2: four radix conversions + four products);
+//   * records arrive as the device's lazy XYZZ values in ITS Montgomery radix 2^(30 NL); one product by 2^(64 N - 30 NL) per
+//     coordinate rescales (and reduces) them on entry, four more make a Jacobian point (Z = ZZZ);
 //   * the Montgomery product is the "no-carry" CIOS for moduli with a clear top bit, fully unrolled (-25 %);
 //   * the records are dealt round-robin to `chains` independent Horner walks (each one: all the doublings, 1/chains of the
 //     additions) that can run on helper threads (bp_internal.hpp: HostPool) and are added at the end; with 4 chains the critical
@@ -180,14 +180,25 @@ private:
         f.add(z3, p.z, q.z); f.sqr(z3, z3); f.sub(z3, z3, z1z1); f.sub(z3, z3, z2z2); f.mul(z3, z3, h);
         memcpy(p.x, x3, sizeof x3); memcpy(p.y, y3, sizeof y3); memcpy(p.z, z3, sizeof z3);
     }
-    // host-form record (see the header of this file): three canonical coordinates in this radix, Z in the `zz` slot; Z = 0 is the identity
-    static Jac from_record(const XyzzPacked<C>& r) {
+    uint64_t dev_to_host[N];   // 2^(128 N - 30 NL) mod p as a plain integer: mul(x_dev, k) = x * 2^(30 NL) * k / 2^(64 N) = x * 2^(64 N)
+
+    // packed words of a device residue (x * 2^(30 NL), any value < 2^(32 NW)) -> this file's Montgomery form, canonical
+    void load(uint64_t* out, const uint32_t* words) const {
+        uint64_t t[N] = {};
+        for (int i = 0; i < Fp::NW; i++) t[i / 2] |= (uint64_t)words[i] << (32 * (i & 1));
+        f.mul(out, dev_to_host, t);
+    }
+    // lazy XYZZ record -> Jacobian with Z = ZZZ (then Z^2 = ZZ^3, Z^3 = ZZZ^3):  X_J = (X / ZZ) ZZ^3 = X ZZ^2,  Y_J = (Y / ZZZ) ZZZ^3 = Y ZZZ^2
+    Jac from_record(const XyzzPacked<C>& r) const {
         Jac p;
         memset(&p, 0, sizeof p);
-        memcpy(p.x, r.x.w, 4 * Fp::NW); memcpy(p.y, r.y.w, 4 * Fp::NW); memcpy(p.z, r.zz.w, 4 * Fp::NW);
-        uint64_t o = 0;
-        for (int i = 0; i < N; i++) o |= p.z[i];
-        p.inf = o == 0;
+        uint64_t X[N], Y[N], ZZ[N], t[N];
+        load(ZZ, r.zz.w);
+        if (f.is_zero(ZZ)) { p.inf = true; return p; }
+        load(X, r.x.w); load(Y, r.y.w); load(p.z, r.zzz.w);
+        f.sqr(t, ZZ); f.mul(p.x, X, t);
+        f.sqr(t, p.z); f.mul(p.y, Y, t);
+        p.inf = false;
         return p;
     }
     static bool is_identity_record(const XyzzPacked<C>& r) {
@@ -198,19 +209,74 @@ private:
 
 public:
     static constexpr int kMaxChains = 8;
-    Tail() {}
+    Tail() {
+        // k = 2^(128 N - 30 NL) mod p, plain integer
+        uint64_t t[N] = {};
+        t[0] = 1;
+        const int e = 128 * N - LB * Fp::NL;
+        for (int i = 0; i < e; i++) {
+            uint64_t carry = t[N - 1] >> 63;
+            for (int j = N - 1; j > 0; j--) t[j] = (t[j] << 1) | (t[j - 1] >> 63);
+            t[0] <<= 1;
+            if (carry || f.geq(t)) f.sub_mod(t);
+        }
+        memcpy(dev_to_host, t, sizeof t);
+    }
 
-    // an affine point (canonical LE words, plain integers) as a host-form record: (x R, y R, R)
-    void record_from_affine(const uint32_t* xw, const uint32_t* yw, XyzzPacked<C>* out) const {
-        memset(out, 0, sizeof *out);
+    // an affine point (canonical LE words, plain integers) as a Jacobian point of this file: (x R, y R, R); all-zero = identity
+    Jac jac_from_affine(const uint32_t* xw, const uint32_t* yw) const {
+        Jac p;
+        memset(&p, 0, sizeof p);
         uint32_t any = 0;
         for (int i = 0; i < Fp::NW; i++) any |= xw[i] | yw[i];
-        if (!any) return;
-        uint64_t x[N] = {}, y[N] = {}, t[N];
+        p.inf = any == 0;
+        if (p.inf) return p;
+        uint64_t x[N] = {}, y[N] = {};
         for (int i = 0; i < Fp::NW; i++) { x[i / 2] |= (uint64_t)xw[i] << (32 * (i & 1)); y[i / 2] |= (uint64_t)yw[i] << (32 * (i & 1)); }
-        f.mul(t, x, f.r2); memcpy(out->x.w, t, 4 * Fp::NW);
-        f.mul(t, y, f.r2); memcpy(out->y.w, t, 4 * Fp::NW);
-        memcpy(out->zz.w, f.one, 4 * Fp::NW);
+        f.mul(p.x, x, f.r2);
+        f.mul(p.y, y, f.r2);
+        memcpy(p.z, f.one, sizeof p.z);
+        return p;
+    }
+
+    // 2^(c w) P for w = 0 .. W1-1 as canonical affine little-endian rows (x || y each; identity = zeros): the rows of ONE point in a
+    // window-multiples table (the per-proof points Q / B_blinding next to the precomputed generators).  c (W1 - 1) Jacobian
+    // doublings and one shared inversion: ~0.1 ms for 16 windows of 16 bits.
+    void window_multiples(const uint8_t* p_le, int c, int W1, uint8_t* rows_le) const {
+        const int fb = 4 * Fp::NW;
+        memset(rows_le, 0, (size_t)W1 * 2 * fb);
+        uint32_t xw[Fp::NW], yw[Fp::NW];
+        memcpy(xw, p_le, fb); memcpy(yw, p_le + fb, fb);
+        Jac acc = jac_from_affine(xw, yw);
+        if (acc.inf || W1 <= 0) return;
+        memcpy(rows_le, p_le, 2 * fb);
+        if (W1 == 1) return;
+        constexpr int kMaxW = 256;
+        static_assert(kMaxW >= 128, "window count of a 2-bit table");
+        if (W1 > kMaxW) W1 = kMaxW;
+        Jac pts[kMaxW];
+        uint64_t pre[kMaxW][N];                       // pre[w] = z_1 ... z_w
+        uint64_t run[N];
+        memcpy(run, f.one, sizeof run);
+        for (int w = 1; w < W1; w++) {
+            for (int k = 0; k < c; k++) dbl(acc);
+            pts[w] = acc;
+            f.mul(run, run, acc.z);
+            memcpy(pre[w], run, sizeof run);
+        }
+        uint64_t inv[N];
+        f.inverse(inv, run);
+        uint64_t onep[N] = {};
+        onep[0] = 1;
+        for (int w = W1 - 1; w >= 1; w--) {
+            uint64_t zi[N], zi2[N], zi3[N], x[N], y[N];
+            if (w > 1) f.mul(zi, inv, pre[w - 1]); else memcpy(zi, inv, sizeof zi);     // 1 / z_w
+            f.mul(inv, inv, pts[w].z);
+            f.sqr(zi2, zi); f.mul(zi3, zi2, zi);
+            f.mul(x, pts[w].x, zi2); f.mul(y, pts[w].y, zi3);
+            f.mul(x, x, onep); f.mul(y, y, onep);                                         // out of Montgomery form
+            memcpy(rows_le + (size_t)w * 2 * fb, x, fb); memcpy(rows_le + (size_t)w * 2 * fb + fb, y, fb);
+        }
     }
 
     // chain `k` of `chains`: Horner over every chains-th non-identity record (in descending bit position), all the way down to bit 0

@@ -287,6 +287,10 @@ struct bp_g1vec {
     // owner's stream order.  Vectors that never leave the library keep the synchronisation-free path.
     bool exported = false;
     struct bp_g1table* table = nullptr;   // window-multiples table built by bp_g1vec_precompute (owned; freed with the vector)
+    // a view over points [tview_off, tview_off + n) of a vector that owns a table (library-internal views: the R1CS prover's
+    // G[0..pn)): lets bp_internal_table_concat copy the rows it needs; never freed through the view
+    const struct bp_g1table* tview = nullptr;
+    size_t tview_off = 0;
 };
 struct bp_frvec {
     bp_ctx* ctx;
@@ -336,6 +340,8 @@ static int host_pinned_reserve(bp_ctx* ctx, size_t bytes) {
 int bp_internal_msm(bp_ctx* ctx, const void* points, const void* scalars, size_t n, uint8_t* out_le, const bp_g1table* tb = nullptr);
 // window-multiples table over n resident points (pool block; bp_internal_table_free)
 int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp_g1table** out);
+// table of [G[offG..+n) | H[offH..+n) | extra] out of the tables of G and H; *out = NULL when they have none (bp_capi.hip)
+int bp_internal_table_concat(bp_ctx* ctx, const bp_g1vec* G, size_t offG, const bp_g1vec* H, size_t offH, size_t n, const uint8_t* extra_le, bp_g1table** out);
 // sibling contexts for independent MSMs in flight (bp_capi.hip)
 extern "C" bp_ctx* bp_internal_helper(bp_ctx* ctx, int k);
 extern "C" int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling);

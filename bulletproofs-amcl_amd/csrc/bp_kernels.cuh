@@ -21,7 +21,7 @@
 //                    per bucket over its chunk sums (lighter multi-task buckets are summed inside k_bucket_reduce)
 //   k_bucket_reduce  compact grid of <= 256 blocks; thread per m consecutive buckets: running sum / sum of running sums,
 //                    weighted by the segment's base value, then an LDS tree per block            -> partial[]
-//   k_window_sums    block per window: tree over the partials                    -> window_sum[W]
+//                    (the last block of a window to finish folds the window's blocks: tail records -> window_sum[])
 //   k_small_msm      n <= kSmallMsmMax terms: the whole device stage in one launch (block per window, lane per term)
 // The final  sum_w 2^(off_w) window_sum[w]  (a strictly serial chain of ~bits doublings) is folded on the host
 // (bp_capi.hip): one lane of a GPU would take ~2 ms for it, the host ~0.1 ms, and the result is needed on the
@@ -519,13 +519,17 @@ __global__ void __launch_bounds__(kBlock) k_combine_heavy(const uint32_t* __rest
 // LDS holds `nplain + 1` arrays of `live` (a power of two <= pitch) packed lazy points: array 0 (the "plane source" X) at
 // lds[0 .. live), plain array a >= 1 at lds[a * pitch ..).  After the call
 //     lds[0]         = sum of X                          lds[a * pitch] = sum of plain array a
-//     lds[1 << k]    = sum of the X[i] with bit k of i set   (k < log2 live)      -- the "bit planes" of X
+//     lds[1 << k]    = sum of the X[i] with bit k of i set   (k < log2 live)      -- the "bit planes" of X (planes == true)
 // in log2(live) steps of ONE dependent addition each: at stride s the upper half of X is not consumed, it stays where it is and
 // becomes the array of plane log2(s), which is then summed like any other array by the following steps.  All arrays alive at a
 // step have the same length 2s, so the step is "slot[b + i] += slot[b + i + s]" over a list of bases b; item q of the step is
 // (base index q / s, i = q % s) and the threads share the items (one per thread while they fit: (nplain + 1 + born) * s <= 256).
+// Code size matters in the kernels around the accumulate loop: an inlined addition is ~50 KB of straight-line code and its first
+// pass is paced by instruction fetch (~100-300 us cold against ~17 us warm), so every kernel here keeps its additions at as few
+// call sites as it can -- this tree has one, and k_bucket_reduce calls it from ONE place for both of its levels.  (A real function
+// shared by all kernels was tried in round 3: the call moves ~200 VGPRs through scratch and quadrupled the reduce, 0.49 -> 2.2 ms.)
 template <class C>
-__device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pitch, int nplain, bool planes = true) {
+__device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pitch, int nplain, bool planes) {
     int born = 0;
 #pragma unroll 1
     for (int s = live >> 1; s >= 1; s >>= 1, born += planes ? 1 : 0) {
@@ -533,7 +537,7 @@ __device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pit
 #pragma unroll 1
         for (int q = (int)threadIdx.x; q < nitems; q += kBlock) {
             const int u = q / s, i = q - u * s;
-            // u = 0: X itself; 1 .. born: the plane born u steps ago ... listed oldest first: plane j (born at stride live >> (j + 1)) sits at that stride
+            // u = 0: X itself; 1 .. born: the plane born u steps ago sits at stride live >> u; then the plain arrays
             const int base = u == 0 ? 0 : u <= born ? (live >> u) : (u - born) * pitch;
             XyzzLazy<C> a = xyzz_lazy_unpack(lds[base + i]);
             a = xyzz_lazy_add(a, xyzz_lazy_unpack(lds[base + i + s]));
@@ -542,6 +546,8 @@ __device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pit
         __syncthreads();
     }
 }
+
+constexpr int kReduceSlots = 3 * kBlock;     // LDS slots of k_bucket_reduce (144 KB for BLS12-381, of the CU's 160 KB: one block per CU, as the grid intends)
 
 // grid = tab.rboff[W] blocks, window w owning blocks rboff[w] .. rboff[w+1]-1 (exactly the blocks that have buckets: with a
 // 2-D grid padded to the widest window, the blocks that exit at once skewed the dispatch and some CUs ran two of these long
@@ -554,83 +560,114 @@ __device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pit
 // has bit k set, and the A_k come out of the SAME tree that sums the block (plane_tree above) at no extra depth.  Each A_k leaves
 // as its own tail record with bit position off_w + lgm + k; the host's Horner walk over bit positions (bp_host_tail.hpp) passes
 // every position anyway, so a plane costs it one addition (~0.5 us) where the device paid 16 us per dependent step.
-// Per block:  partial[bid * kPartPerBlock + 0] = sum tri, [1] = sum run, [2 + k] = plane of thread-index bit k (k < log2 live).
+// Two levels, one kernel: every block leaves [sum tri | sum run | planes of its 8 thread-index bits] in partial[], and the LAST
+// block of a window to finish (a counter per window) folds the window's blocks: plain sums of tri and of the thread-bit planes,
+// and the planes of the blocks' run totals over the BLOCK index (the upper bits of the thread index).  A separate second kernel
+// for that cost 146 us per MSM for two additions (cold code, see plane_tree); here the tree's code is already warm.
+// Records of window w (lazy XYZZ, packed), at window_sum[roff[w] ..]:  tri | thread-bit planes | block-bit planes.
 // Bucket g's sum is tsum[task_off[g]] (identity when it has no task).
 // (Round 2 tried plain "digit sums" of the bucket values instead -- lost: profiles/r02_digit_sum_experiment.txt.)
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* __restrict__ tsum, const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ ntasks, WinTab tab,
-                                                          XyzzPacked<C>* __restrict__ partial) {
-    __shared__ XyzzPacked<C> lds[2 * kBlock];
+                                                          XyzzPacked<C>* __restrict__ partial, uint32_t* __restrict__ done,
+                                                          XyzzPacked<C>* __restrict__ window_sum) {
+    __shared__ XyzzPacked<C> lds[kReduceSlots];
+    __shared__ uint32_t s_last;
     const uint32_t bid = blockIdx.x;
     uint32_t w = 0;
     while (w + 1 < (uint32_t)tab.W && tab.rboff[w + 1] <= bid) w++;   // uniform scan, W <= 256
-    const uint32_t bx = bid - tab.rboff[w], lgm = tab.lgm[w], m = 1u << lgm;
+    const uint32_t first = tab.rboff[w], nblk = tab.rboff[w + 1] - first;
+    const uint32_t bx = bid - first, lgm = tab.lgm[w], m = 1u << lgm;
     const uint32_t B = tab.boff[w + 1] - tab.boff[w];
     const uint32_t T = B >> lgm;                                       // threads of the window: a power of two
     const uint32_t t = bx * kBlock + threadIdx.x;
     const int live = T < (uint32_t)kBlock ? (int)T : kBlock;
+    int lgT = 0, lgB = 0;
+    while ((1 << lgT) < live) lgT++;
+    while ((1u << lgB) < nblk) lgB++;
+    // ---- per-thread running sums: ONE addition site; an "operation" is  run += (a task sum)  or  tri += run
     XyzzLazy<C> run = xyzz_lazy_inf<C>(), tri = xyzz_lazy_inf<C>();
     if (t < T) {
         const uint32_t lo = t * m;
-        for (uint32_t j = lo + m; j-- > lo;) {
-            const uint32_t g = tab.boff[w] + j;
-            const uint32_t nt = ntasks[g];
-            if (nt) {
+        uint32_t j = lo + m;                 // buckets are walked downwards: j - 1 is the current one
+        uint32_t k = 0, lim = 0, t0 = 0;     // task sums of the current bucket still to add: k .. lim - 1 at tsum[t0 + k]
+        bool fresh = true;                   // the current bucket has not been looked at yet
+#pragma unroll 1
+        while (j > lo) {
+            if (fresh) {
+                const uint32_t g = tab.boff[w] + j - 1;
+                const uint32_t nt = ntasks[g];
                 // a bucket cut into 2..kLightMax tasks is summed here (a separate lane-per-bucket kernel for it cost 0.1-0.2 ms
                 // at n = 2^16); a heavier bucket was already folded into its first record by k_combine_chunks / _heavy
-                const uint32_t t0 = task_off[g], lim = nt <= kLightMax ? nt : 1;
-                for (uint32_t k = 0; k < lim; k++) run = xyzz_lazy_add(run, xyzz_lazy_unpack(tsum[t0 + k]));
+                lim = nt == 0 ? 0 : nt <= kLightMax ? nt : 1;
+                t0 = nt ? task_off[g] : 0;
+                k = 0;
+                fresh = false;
             }
-            tri = xyzz_lazy_add(tri, run);
+            const bool take = k < lim;       // run += tsum[t0 + k]   else   tri += run, next bucket
+            XyzzLazy<C> a = take ? run : tri;
+            const XyzzLazy<C> b = take ? xyzz_lazy_unpack(tsum[t0 + k]) : run;
+            a = xyzz_lazy_add(a, b);
+            if (take) { run = a; k++; }
+            else { tri = a; j--; fresh = true; }
         }
     }
+    // ---- two tree levels through ONE call of plane_tree: pass 0 = this block, passes >= 1 = the window (last block only)
     if ((int)threadIdx.x < live) {
         lds[threadIdx.x] = xyzz_lazy_pack(run);
         lds[kBlock + threadIdx.x] = xyzz_lazy_pack(tri);
     }
     __syncthreads();
-    plane_tree<C>(lds, live, kBlock, 1);
-    int lg = 0;
-    while ((1 << lg) < live) lg++;
-    if ((int)threadIdx.x < 2 + lg) {
-        const int k = (int)threadIdx.x;
-        partial[(size_t)bid * kPartPerBlock + k] = k == 0 ? lds[kBlock] : k == 1 ? lds[0] : lds[1 << (k - 2)];
-    }
-}
-
-// Second level, grid = (windows, kPartPerBlock): block (w, a) folds ONE kind of partial over the nblk = rboff[w+1] - rboff[w]
-// blocks of window w (nblk is a power of two) into the window's tail records  [tri | thread-bit planes | block-bit planes]:
-//   a = 0              sum of the blocks' tri                               -> record 0
-//   a = 2 + k          sum of the blocks' planes of thread bit k            -> record 1 + k
-//   a = 1              the blocks' run totals: their planes over the BLOCK index (bits log2(256).. of the thread index)
-//                                                                           -> records 1 + lgT .. (the total itself is not a record)
-// HOSTREC: records leave in the host's form (xyzz_lazy_to_host_record) -- the normal case; false keeps them as lazy XYZZ for the
-// device-side tail (k_tail_fold).
-template <class C, bool HOSTREC>
-__global__ void __launch_bounds__(kBlock) k_window_sums(const XyzzPacked<C>* __restrict__ partial, WinTab tab, XyzzPacked<C>* __restrict__ window_sum) {
-    __shared__ XyzzPacked<C> lds[kBlock];
-    const uint32_t w = blockIdx.x, a = blockIdx.y;
-    const uint32_t first = tab.rboff[w], nblk = tab.rboff[w + 1] - first;
-    const uint32_t B = tab.boff[w + 1] - tab.boff[w], T = B >> tab.lgm[w];
-    const uint32_t live = T < (uint32_t)kBlock ? T : (uint32_t)kBlock;
-    int lgT = 0, lgB = 0;
-    while ((1u << lgT) < live) lgT++;
-    while ((1u << lgB) < nblk) lgB++;
-    if (a >= 2u + (uint32_t)lgT) return;                      // this window has fewer thread-bit planes
     XyzzPacked<C>* rec = window_sum + tab.roff[w];
-    if (a == 1 && lgB == 0) return;                           // one block: its run total is not needed
-    if (threadIdx.x < nblk) lds[threadIdx.x] = partial[(size_t)(first + threadIdx.x) * kPartPerBlock + a];
-    __syncthreads();
-    plane_tree<C>(lds, (int)nblk, kBlock, 0, a == 1);         // sum at lds[0]; for a = 1 the block-bit planes at lds[1 << k]
-    if (a == 1) {
-        if ((int)threadIdx.x < lgB) {
-            const XyzzPacked<C> v = lds[1u << threadIdx.x];
-            rec[1 + lgT + threadIdx.x] = HOSTREC ? xyzz_lazy_to_host_record(xyzz_lazy_unpack(v)) : v;
+    const int narr = 1 + lgT;                                   // plain arrays of the window level: tri and the thread-bit planes
+    int per = (int)(kReduceSlots / nblk);                       // arrays of nblk entries that fit the LDS at once
+    if (per > narr + 1) per = narr + 1;
+    int next_arr = 0;                                           // window level: next partial kind (0 = run totals, 1 = tri, 2 + k = plane k) to fold
+    int tree_live = live, tree_pitch = kBlock, tree_plain = 1;
+    bool tree_planes = true;
+#pragma unroll 1
+    for (int pass = 0;; pass++) {
+        plane_tree<C>(lds, tree_live, tree_pitch, tree_plain, tree_planes);
+        if (pass == 0) {
+            if (nblk == 1) {                                    // one block: its sums are the window's records
+                if ((int)threadIdx.x <= lgT) rec[threadIdx.x] = threadIdx.x == 0 ? lds[kBlock] : lds[1u << (threadIdx.x - 1)];
+                return;
+            }
+            if ((int)threadIdx.x < 2 + lgT) {
+                const int q = (int)threadIdx.x;                 // partial kinds: 0 = sum run, 1 = sum tri, 2 + k = plane of thread bit k
+                partial[(size_t)bid * kPartPerBlock + q] = q == 0 ? lds[0] : q == 1 ? lds[kBlock] : lds[1u << (q - 2)];
+            }
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) s_last = atomicAdd(&done[w], 1u) == nblk - 1 ? 1u : 0u;
+            __syncthreads();
+            if (!s_last) return;
+            __threadfence();
+        } else {
+            // results of the group just folded: kinds [grp0, next_arr); kind 0 sits at lds[0] with its planes, kind q at slot (q - grp0) * nblk
+            const int grp0 = next_arr - tree_plain - 1;         // the group held tree_plain + 1 arrays
+            if (tree_planes && (int)threadIdx.x < lgB) rec[1 + lgT + threadIdx.x] = lds[1u << threadIdx.x];     // block-bit planes of the run totals
+            const int nres = next_arr - grp0;
+            if ((int)threadIdx.x < nres) {
+                const int q = grp0 + (int)threadIdx.x;
+                if (q >= 1) rec[q - 1] = lds[(size_t)threadIdx.x * nblk];        // kind 1 (tri) -> record 0, kind 2 + k -> record 1 + k
+            }
+            if (next_arr > narr) return;
+            __syncthreads();
         }
-    } else if (threadIdx.x == 0) {
-        const XyzzPacked<C> v = lds[0];
-        rec[a == 0 ? 0 : a - 1] = HOSTREC ? xyzz_lazy_to_host_record(xyzz_lazy_unpack(v)) : v;
+        // load the next group of partial kinds: entry bx2 of kind q from partial[(first + bx2) * kPartPerBlock + q]
+        const int take = narr + 1 - next_arr < per ? narr + 1 - next_arr : per;
+        for (int e = (int)threadIdx.x; e < take * (int)nblk; e += kBlock) {
+            const int qa = e / (int)nblk, bx2 = e - qa * (int)nblk;
+            lds[(size_t)qa * nblk + bx2] = partial[(size_t)(first + bx2) * kPartPerBlock + next_arr + qa];
+        }
+        tree_planes = next_arr == 0;                            // only the run totals (kind 0) spawn planes
+        tree_plain = take - 1;
+        tree_live = (int)nblk;
+        tree_pitch = (int)nblk;
+        next_arr += take;
+        __syncthreads();
     }
 }
 
@@ -648,7 +685,7 @@ __device__ __forceinline__ uint32_t window_bits(const uint64_t (&q)[4], int off,
     return (uint32_t)v & ((1u << cw) - 1);
 }
 
-template <class C, bool HOSTREC>
+template <class C>
 __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __restrict__ pts, const ScalarWords* __restrict__ sc1,
                                                       const ScalarWords* __restrict__ sc2, uint32_t n, WinTab tab,
                                                       XyzzPacked<C>* __restrict__ window_sum) {
@@ -672,7 +709,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         mine = xyzz_lazy_add(mine, acc);
     }
     mine = block_tree_sum<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
-    if (threadIdx.x == 0) window_sum[tab.roff[w]] = HOSTREC ? xyzz_lazy_to_host_record(mine) : xyzz_lazy_pack(mine);
+    if (threadIdx.x == 0) window_sum[tab.roff[w]] = xyzz_lazy_pack(mine);
 }
 
 // ---------------------------------------------------------------------------------------------- device tail (optional)

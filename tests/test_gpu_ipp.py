@@ -233,6 +233,30 @@ def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf, prover_mode):
                         proof.L, proof.R, proof.lg_n) == 0
 
 
+@pytest.mark.parametrize("name,n,c", [("bls12_381", 256, 0), ("bls12_381", 1024, 11), ("bn254", 512, 16), ("bn254", 2048, 9)])
+def test_ipp_with_precomputed_generators(bp, ctxs, name, n, c):
+    """bp_g1vec_precompute on G and H: every round's L / R is a merged-window MSM over [G | H | Q] rows -- the proof must be the
+    oracle's byte for byte (and the one produced without tables), mismatched table widths fall back to the plain pipeline."""
+    ctx = ctxs[name]
+    cid = ctx.curve
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 21000 + n, unit_gf=False)
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(),
+                            b.to_bytes(), n)
+    assert rc == 0
+    plain = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert (plain.L, plain.R, plain.a, plain.b) == want
+    Gv.precompute(c)
+    Hv.precompute(c)
+    assert Gv.table_info()[0] == Hv.table_info()[0] != 0
+    tabled = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert (tabled.L, tabled.R, tabled.a, tabled.b) == want
+    Hv.precompute(12 if Gv.table_info()[0] != 12 else 10)             # widths differ: no table for the concatenation
+    mixed = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert (mixed.L, mixed.R, mixed.a, mixed.b) == want
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, tabled.a, tabled.b, tabled.L, tabled.R)
+
+
 @pytest.mark.parametrize("name", CURVES)
 def test_ipp_round_api_with_external_transcript(bp, ctxs, name, prover_mode):
     """The low-level state API driven by a transcript the caller owns (here: the oracle's), as a Rust host would."""

@@ -227,6 +227,14 @@ def test_cfg3_full_chain_vs_oracle(bp):
         # 2. the oracle's prover (reference-shaped: it folds the generators every round) produces the same bytes
         rc, want = O.r1cs_prove(cid, O.r1cs_start_transcript(cid, b"cfg3", V), T, g, h, Gb, Hb, n, aL, aR, aO, vb, sL, sR, bl)
         assert rc == 0 and proof == want
+        # 2b. with window-multiples tables on the generators (bp_g1vec_precompute: merged-window MSMs for the commitments and every
+        # IPP round) the prover must produce the same bytes
+        Gv.precompute(16)
+        Hv.precompute(16)
+        assert Gv.table_info()[:2] == (16, 16)
+        proof_t = bp.r1cs_prove(ctx, start_transcript(bp, ctx, b"cfg3", V), plan, Gv, Hv, g, h, fe(aL, n), fe(aR, n), fe(aO, n), fe(vb, m), fe(sL, n),
+                                fe(sR, n), bl)
+        assert proof_t == want
         # 3. the library's verifier accepts it, and both reject a changed proof / statement
         bp.r1cs_verify(ctx, start_transcript(bp, ctx, b"cfg3", V), plan, Gv, Hv, g, h, Vb, n, proof, rnd)
         pb = ctx.point_bytes
@@ -265,6 +273,14 @@ def test_ipp_2p16_vs_oracle(bp):
         proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"ipp 2^16"), Q, fe(Gf), fe(Hf), Gv, Hv, fe(a), fe(b))
         rc, want = O.ipp_create(cid, O.Transcript(b"ipp 2^16"), Q, Gf, Hf, Gb, Hb, a, b, n)
         assert rc == 0 and (proof.L, proof.R, proof.a, proof.b) == want
+        # the same proof with precomputed generators (every round a merged-window MSM over the tables), two table widths
+        for c in (16, 13):
+            Gv.precompute(c)
+            Hv.precompute(c)
+            pt = bp.IPP.create_ipp(ctx, bp.Transcript(b"ipp 2^16"), Q, fe(Gf), fe(Hf), Gv, Hv, fe(a), fe(b))
+            assert (pt.L, pt.R, pt.a, pt.b) == want, c
+        Gv.drop_table()
+        Hv.drop_table()
         # P = <a, Gf o G> + <b, Hf o H> + <a, b> Q (src/ipp.rs:353-372) and both verifiers
         sc = fe(a).hadamard_product(fe(Gf)).to_bytes() + fe(b).hadamard_product(fe(Hf)).to_bytes() + fe(a).inner_product(fe(b))
         P = bp.G1Vector.from_bytes(ctx, pts, 2 * n + 1).multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, sc, 2 * n + 1))
