@@ -48,14 +48,35 @@ def random_scalars(r, bits, n, seed):
     return out.tobytes()
 
 
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching the HIP runtime (the launcher must never initialise it: it only ever starts
+    child processes).  KFD topology nodes with SIMDs are GPUs; a *_VISIBLE_DEVICES list narrows them.  None = unknown."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
-    """--gpus N > 1 without a process group in the environment: start N ranks (one per GPU) and relay rank 0's JSON line.
-    Nothing in this process has touched the GPU (counting devices does not initialise it)."""
+    """--gpus N > 1 without a process group in the environment: start N ranks (one per GPU) as CHILD processes and relay rank 0's
+    JSON line.  This process never imports torch and never calls into HIP; it must only ever spawn children (an exec from a process
+    that has initialised the GPU takes the machine down on this pool).  To profile the ranks, put rocprofv3 around an external
+    `python -m torch.distributed.run ... bench.py`, not around this launcher (scripts/README.md)."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus and not args.rehearse_one_device:
+    have = visible_gpu_count()
+    if have is not None and have < args.gpus and not args.rehearse_one_device:
         print("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have), file=sys.stderr)
         return 2
     with socket.socket() as sock:
@@ -72,6 +93,96 @@ def self_launch(args):
     return p.returncode if p.returncode else (0 if lines else 1)
 
 
+def size_sweep(bp, ctx, curve, info, unit_bytes, lgs=(16, 17, 18, 19, 20, 21, 22), reps=5):
+    """MSM over the first 2^lg of one resident 2^22-point input set, best of `reps` wall-clock runs per size (inputs resident in
+    HBM, result on the host), each result checked by linearity:  MSM(s, k.G) == (<s, k> mod r).G  with the oracle as the checker."""
+    import _oracle as O
+    nmax = 1 << max(lgs)
+    kb = random_scalars(ctx.r, info.fr_bits, nmax, 0x5EE9)
+    sb = random_scalars(ctx.r, info.fr_bits, nmax, 0x5EEA)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, kb, nmax))
+    sv = bp.FieldElementVector.from_bytes(ctx, sb, nmax)
+    ctx.synchronize()
+    out = {}
+    for lg in lgs:
+        n = 1 << lg
+        got = pts.msm_range(0, sv, 0, n)
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            got = pts.msm_range(0, sv, 0, n)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        want = O.g1_mul(curve, O.fr_inner(curve, kb[: 32 * n], sb[: 32 * n], n), O.generator(curve))
+        out["2^%d" % lg] = {"ms": round(best * 1e3, 4), "scalar_muls_per_s": round(n / best, 1), "algorithmic_GBs": round(n * unit_bytes / best / 1e9, 2),
+                            "verified": bool(got == want)}
+    pts.free()
+    sv.free()
+    ctx.trim()
+    return out
+
+
+def strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=22, steps=5, warmup=1):
+    """BASELINE config 4 inside the weak run: 2^22 points IN TOTAL split by index range over the ranks, timed like the main value
+    (barrier + synchronize on both sides, max over ranks) and verified against the oracle on rank 0."""
+    import _oracle as O
+    n_total = 1 << lg_total
+    lo, hi = sharding.shard_range(n_total, world, rank)
+    n = hi - lo
+    n_set = sharding.largest_shard(n_total, world)
+    if n_total % world:
+        ctx.set_window_bits(sharding.common_window_bits(bp, curve, n_total, world))
+    seed_of = lambda rk: 0xC0F164 + 2 * rk
+    kb = random_scalars(ctx.r, info.fr_bits, n, seed_of(rank))
+    sb = random_scalars(ctx.r, info.fr_bits, n, seed_of(rank) + 1)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, kb, n))
+    sv = bp.FieldElementVector.from_bytes(ctx, sb, n)
+    ctx.synchronize()
+    W = bp.msm_window_records(ctx, n_set)
+    mine = torch.zeros(W * bp.msm_record_bytes(curve), dtype=torch.uint8, device=dev)
+
+    def step():
+        bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
+        allrec = sharding.all_gather_records(mine, world)
+        torch.cuda.current_stream(dev).synchronize()
+        return bp.msm_finish(ctx, allrec.data_ptr(), world, n_set)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        result = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        result = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_device else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ctx.set_window_bits(0)
+    out = None
+    if rank == 0:
+        acc = 0
+        for rk in range(world):
+            a, b = sharding.shard_range(n_total, world, rk)
+            k2 = kb if rk == 0 else random_scalars(ctx.r, info.fr_bits, b - a, seed_of(rk))
+            s2 = sb if rk == 0 else random_scalars(ctx.r, info.fr_bits, b - a, seed_of(rk) + 1)
+            acc = (acc + int.from_bytes(O.fr_inner(curve, k2, s2, b - a), "little")) % ctx.r
+        want = O.g1_mul(curve, acc.to_bytes(32, "little"), O.generator(curve))
+        ok = bool(result == want)
+        out = {"workload": "2^%d-point bls12_381 G1 MSM in total, index range split over %d GPUs (BASELINE config 4 shape)" % (lg_total, world),
+               "scaling": "strong", "n_total": n_total, "n_per_gpu": n_set, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+               "value": n_total * steps / elapsed if ok else None, "unit": "scalar-muls/s", "verified": ok,
+               "speedup_vs_1gpu_same_n": None,       # needs the N = 1 run's sweep["2^22"]: the driver has both lines, this one has not
+               "one_gpu_reference": "sweep[\"2^%d\"] of the --gpus 1 line" % lg_total}
+    pts.free()
+    sv.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +193,10 @@ def main():
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra keys of the default line (N = 1: \"sweep\" over 2^16..2^22; N > 1: \"strong_2p22\")")
+    ap.add_argument("--extras", action="store_true", help="emit the extra keys although --lg-n is not the headline size (tests)")
+    ap.add_argument("--sweep-max-lg", type=int, default=22, help="largest size of the N = 1 sweep (tests shrink it)")
+    ap.add_argument("--strong-lg", type=int, default=22, help="log2 of the total size of the N > 1 strong-scaling extra (tests shrink it)")
     ap.add_argument("--overlap", action="store_true",
                     help="also time the same MSMs with two in flight (extra field; off by default so that rocprofv3 averages of the default "
                          "command are not mixed with concurrently running kernels)")
@@ -121,13 +236,21 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
+            import datetime
+            tmo = datetime.timedelta(seconds=120)
             if args.rehearse_one_device:
-                dist.init_process_group(backend="gloo")
+                dist.init_process_group(backend="gloo", timeout=tmo)
             else:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                if local_rank >= torch.cuda.device_count():
+                    raise RuntimeError("rank %d: local rank %d has no GPU (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
             torch.cuda.set_device(local_rank)
             dist.barrier()
             torch.cuda.synchronize()
+        except Exception as e:      # never a hang, never a retry: one line and a non-zero exit
+            print("bench.py: rank %d could not join the %d-rank process group (%s backend): %s" % (rank, world, "gloo" if args.rehearse_one_device else "nccl/RCCL", e),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -244,13 +367,13 @@ def main():
         # library being benchmarked (profiles/README lists how it was taken); raw FETCH_SIZE + WRITE_SIZE (the guide's x2 read
         # correction is calibrated for wide streaming reads, not for 96-byte row gathers, so it is not applied).
         traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_bench_n1_pmc_hbm.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_bench_n1_pmc_hbm.json")
         if args.curve == "bls12_381" and args.lg_n == 20 and not args.strong and os.path.exists(pmc):
             pj = json.load(open(pmc))
             k = next((v for name, v in pj.get("kernels", {}).items() if ACC_KERNEL_PREFIX in name), {})
             if "FETCH_SIZE_KiB_avg" in k and "WRITE_SIZE_KiB_avg" in k:
                 traffic = int((k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
-                traffic_note = "stored profile profiles/r02_bench_n1_pmc_hbm.json (%s): raw FETCH_SIZE + WRITE_SIZE per launch" % pj.get("taken", "?")
+                traffic_note = "stored profile profiles/r03_bench_n1_pmc_hbm.json (%s): raw FETCH_SIZE + WRITE_SIZE per launch" % pj.get("taken", "?")
         if acc_ms:
             avg = float(np.mean(acc_ms)) * 1e-3
             achieved = n * unit_bytes / avg / 1e9
@@ -260,16 +383,17 @@ def main():
                         "pipeline_GBs": round(n * unit_bytes / (float(np.mean(dev_ms)) * 1e-3) / 1e9, 2)}
             # The kernel is integer-ALU bound, so the HBM fraction says little about it.  Beside it: the rate of mixed additions
             # against (a) the instruction-ISSUE ceiling -- the kernel's mixed addition is 6 products + 2 squares + one two-product /
-            # one-reduction form (bp_curve.cuh: xyzz_lazy_add_aff) = 6 x 351 + 2 x 273 + 520 = 3172 multiply-class instructions
+            # one-reduction form (bp_curve.cuh: xyzz_lazy_add_aff_fast) with the fused Montgomery core of round 3
+            # (bp_field.cuh: mont_core; per product 169 + 169 + 3 mads + 13 v_mul_lo) = 6 x 354 + 2 x 276 + 549 = 3225 multiply-class instructions
             # (v_mad_u64_u32 / v_mul_lo) at the measured 4.5 cycles per wave64 instruction per SIMD, 1024 SIMDs at 2.4 GHz, nothing
             # else counted -- and (b) the multiply-instruction rate this library's own multiplier loop sustains
             # (microbench/fpmul_rate.hip: 6.6e10 products/s x 351).
             if args.curve == "bls12_381":
                 adds = n * n_windows / avg
-                mul_instr = 6 * 351 + 2 * 273 + 520
+                mul_instr = 6 * 354 + 2 * 276 + 549
                 issue_peak = 1024 * 64 * 2.4e9 / (mul_instr * 4.5)
                 roofline["alu"] = {"achieved": round(adds, 0), "unit": "mixed additions/s", "peak": round(issue_peak, 0), "frac": round(adds / issue_peak, 4),
-                                   "how": "n * windows additions / kernel time; peak = issue limit of the multiply instructions alone (6*351 + 2*273 + 520 = 3172 per addition, "
+                                   "how": "n * windows additions / kernel time; peak = issue limit of the multiply instructions alone (6*354 + 2*276 + 549 = 3225 per addition, "
                                           "4.5 cyc per wave64 instruction, 1024 SIMDs, 2.4 GHz)",
                                    "vs_own_multiplier_microbench": round(adds * mul_instr / (6.6e10 * 351), 4)}
         out = {
@@ -327,6 +451,16 @@ def main():
         chk = pts.msm_range(0, sv, 0, ns)
         out["cpu_baseline"]["matches_gpu"] = bool(chk == r1)
 
+    # ---- extras in the SAME line (never `value`): what the driver's one command would otherwise not measure -------
+    #   N = 1: the n = 2^16 .. 2^22 sweep of north_star (best of 5 each, every size verified by linearity)
+    #   N > 1: BASELINE config 4 -- a 2^22-point MSM split by index range over the N ranks (strong scaling)
+    extras = not args.no_extras and not args.strong and args.curve == "bls12_381" and (args.lg_n == 20 or args.extras) and not failed
+    if extras and world == 1:
+        out["sweep"] = size_sweep(bp, ctx, curve, info, unit_bytes, lgs=tuple(range(min(16, args.sweep_max_lg), args.sweep_max_lg + 1)))
+    if extras and world > 1:
+        st = strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=args.strong_lg)
+        if rank == 0:
+            out["strong_2p%d" % args.strong_lg] = st
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -29,6 +29,30 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["matches_gpu"] is True and "sample" in c
     assert abs(d["value"] - (1 << 14) * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert "sweep" not in d                                        # the extras belong to the headline size (or --extras)
+
+
+def test_bench_extras_sweep_and_strong_keys():
+    """The driver runs ONE command per N; the line must therefore carry what north_star asks beside the headline:
+    N = 1 -> "sweep" (sizes up to 2^22 in the real run; shrunk here), N > 1 -> "strong_2p22" (BASELINE config 4; shrunk, and on this
+    one-GPU box in rehearsal mode).  Every entry is verified against the oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lg-n", "14", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--extras",
+                        "--sweep-max-lg", "17"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    sw = d["sweep"]
+    assert sorted(sw) == ["2^16", "2^17"]
+    for e in sw.values():
+        assert e["verified"] is True and e["ms"] > 0 and e["scalar_muls_per_s"] > 0 and e["algorithmic_GBs"] > 0
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lg-n", "14", "--steps", "2", "--warmup", "1", "--extras",
+                        "--strong-lg", "16", "--rehearse-one-device"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["scaling"] == "weak" and d["verified"] is True and "sweep" not in d
+    st = d["strong_2p16"]
+    assert st["scaling"] == "strong" and st["n_total"] == 1 << 16 and st["n_per_gpu"] == 1 << 15 and st["verified"] is True
+    assert st["value"] > 0 and st["speedup_vs_1gpu_same_n"] is None
 
 
 def test_bench_self_launches_n_ranks_and_strong_scaling():
