@@ -202,10 +202,10 @@ def bound_check_chain(r, checks, bits, rng, triples=None):
 
 def cfg3_e2e():
     """BASELINE config 3 end to end: R1CS proof of 1024 chained 32-bit bound checks (2^16 multiplication gates), created and
-    verified through bulletproofs-amcl_amd/r1cs.py -- the host-side mirror of Prover::prove / Verifier::verify over the C ABI.
+    verified through tests/r1cs_twin.py -- the host-side mirror of Prover::prove / Verifier::verify over the C ABI.
     Untimed setup: generators (get_generators), the per-circuit constraint plan, the witness upload and the 3 072 Pedersen
     commitments V of the statement; timed: everything from the first transcript operation to the proof / the verdict."""
-    from bulletproofs_amcl_amd import r1cs as R1
+    import r1cs_twin as R1
     ctx = bp.Context(bp.BLS12_381, 0)
     info = bp.curve_info(ctx.curve)
     r = ctx.r
@@ -246,7 +246,7 @@ def cfg3_e2e():
         except bp.VerificationError:
             return False
 
-    def py_prove():       # the same orchestration in the Python mirror (r1cs.py)
+    def py_prove():       # the same orchestration in the Python mirror (tests/r1cs_twin.py)
         return R1.prove(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), dAL, dAR, dAO, dVB, sL, sR, bl)
 
     t0 = time.perf_counter()

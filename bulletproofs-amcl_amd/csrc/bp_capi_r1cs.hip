@@ -2,7 +2,7 @@
 // of this library (include/bpmsm.h) plus host field arithmetic: `Prover::prove` (/root/reference src/r1cs/prover.rs:323-560)
 // and `Verifier::verify` (src/r1cs/verifier.rs:265-452) for single-phase constraint systems (n2 = 0: A_I2 = A_O2 = S2 = O).
 // The host keeps the transcript and a handful of scalars, exactly the reference's split; everything with a vector or a group
-// element in it is a bp_* call.  bulletproofs-amcl_amd/r1cs.py is the same orchestration in the Python mirror; the tests
+// element in it is a bp_* call.  tests/r1cs_twin.py is the same orchestration in the Python mirror; the tests
 // require both to produce the same proof bytes.
 #include <vector>
 

@@ -32,7 +32,7 @@ while time.time() < t_end:
     elif kind == "r1cs":
         # random satisfiable single-phase circuit: bp_r1cs_prove (C++ in the library) == the Python mirror byte for byte,
         # both verifiers accept, and a flipped byte anywhere in the proof is rejected
-        from bulletproofs_amcl_amd import r1cs as R1
+        import r1cs_twin as R1
         r = ctx.r
         n = rnd.choice([1, 2, 3, 5, 8, 13, 31, 64, 100]); m = rnd.choice([0, 1, 2, 5]); nq = rnd.randrange(0, 3 * n + 2)
         aL = [rnd.randrange(r) for _ in range(n)]; aR = [rnd.randrange(r) for _ in range(n)]; aO = [x * y % r for x, y in zip(aL, aR)]

@@ -9,10 +9,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as G  # noqa: E402
 
 bp = G.load_package()
-from bulletproofs_amcl_amd import r1cs as R1  # noqa: E402
+import r1cs_twin as R1  # noqa: E402
 from bench import random_scalars  # noqa: E402
 from bench_configs import bound_check_chain  # noqa: E402
 

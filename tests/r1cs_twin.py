@@ -1,4 +1,8 @@
-"""Host-side mirror of the two callers of the hot path in the R1CS layer: `Prover::prove` (reference src/r1cs/prover.rs:323-560)
+"""TEST SCAFFOLDING (moved out of the package in round 3): a Python twin of the library's R1CS orchestration, kept so that the
+tests can require two independently written orchestrations over the same C ABI to produce identical bytes.  The product path is
+csrc/bp_capi_r1cs.hip (bp_r1cs_prove / bp_r1cs_verify), pinned by the independent oracle (oracle/orc_r1cs_tmpl.h, oracle/pyref.py).
+
+Host-side mirror of the two callers of the hot path in the R1CS layer: `Prover::prove` (reference src/r1cs/prover.rs:323-560)
 and `Verifier::verify` (src/r1cs/verifier.rs:265-452), for single-phase constraint systems (no randomised second phase:
 n2 = 0 and A_I2 = A_O2 = S2 = identity).
 

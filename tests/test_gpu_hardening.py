@@ -252,3 +252,92 @@ def test_r1cs_proof_compressed_form(bp, golden):
                 bp.r1cs_proof_decompress(ctx, n, bytes(bad))
         ctx.close()
     assert bp.lib().bp_r1cs_proof_compressed_bytes(0, 1 << 16) == 2267 and bp.lib().bp_r1cs_proof_bytes(0, 1 << 16) == 4288
+
+
+def test_tuning_knobs_are_validated_and_the_environment_changes_nothing(bp):
+    """until round 2 BP_TILE / BP_REDUCE_M / BP_TASK_TARGET / ... were environment variables used as they were
+    (BP_TILE=1000 silently dropped scalars).  Now: the library reads no environment variable that can change a result, and the
+    knobs are per-context setters that refuse bad values.  Every accepted setting must give the oracle's bytes."""
+    import os, subprocess, sys
+    cid = 0
+    ctx = bp.Context(cid, 0)
+    n = 20000
+    ks, ss = O.random_scalars(cid, 61, n), O.random_scalars(cid, 62, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+    want = O.msm(cid, pts.to_bytes(), ss, n, algo=O.PIPPENGER, nthreads=8)
+    assert pts.multi_scalar_mul_var_time(sv) == want
+    for knob, bad in ((bp.TUNE_TILE, (1000, 255, 300, 16384 + 256, -1)), (bp.TUNE_REDUCE_M, (3, 6, 1 << 15, -2)), (bp.TUNE_TASK_TARGET, (5, 1 << 29)),
+                      (bp.TUNE_SMALL_MSM, (2, 7)), (99, (1,))):
+        for v in bad:
+            with pytest.raises(bp.ArgError):
+                ctx.set_tuning(knob, v)
+        assert pts.multi_scalar_mul_var_time(sv) == want
+    for knob, good in ((bp.TUNE_TILE, (256, 1024, 16384, 0)), (bp.TUNE_REDUCE_M, (1, 2, 16, 64, 0)), (bp.TUNE_TASK_TARGET, (1024, 1 << 20, 0)),
+                       (bp.TUNE_SMALL_MSM, (0, 1))):
+        for v in good:
+            ctx.set_tuning(knob, v)
+            assert pts.multi_scalar_mul_var_time(sv) == want, (knob, v)
+            small = pts.msm_range(0, sv, 0, 300)
+            assert small == O.msm(cid, pts.to_bytes(0, 300), ss[:300 * 32], 300, algo=O.PIPPENGER), (knob, v)
+    ctx.close()
+    # the variables of rounds 1-2, set to values that used to corrupt results, are ignored (fresh process: they were read once)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BP_TILE="1000", BP_REDUCE_M="3", BP_GROUPS="5", BP_TASK_TARGET="7", BP_ACC_WPS="9", BP_SMALL_MSM="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_msm.py"), "3", "77"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "fails 0" in p.stdout.splitlines()[-1], p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_exported_vector_is_safe_to_free_while_a_view_computes(bp):
+    """freed blocks go back to the context's pool without synchronising, which is only sound while every use is
+    ordered on the owner's stream.  A vector whose raw pointer was handed out (device_ptr: torch / RCCL / a view on ANOTHER context)
+    now waits for the device when it is freed: free the owner while the view's MSM is in flight, recycle the block at once with
+    new contents, and the view's result must still be the old vector's."""
+    cid = 0
+    owner, other = bp.Context(cid, 0), bp.Context(cid, 0)
+    n = 1 << 18
+    ks, ss = O.random_scalars(cid, 71, n), O.random_scalars(cid, 72, n)
+    pts = bp.G1Vector.fixed_base(owner, bp.FieldElementVector.from_bytes(owner, ks, n))
+    sv = bp.FieldElementVector.from_bytes(owner, ss, n)
+    want = O.g1_mul(cid, O.fr_inner(cid, ks, ss, n), O.generator(cid))
+    owner.synchronize()
+    pview = bp.G1Vector.wrap_device(other, pts.device_ptr(), n)
+    sview = bp.FieldElementVector.wrap_device(other, sv.device_ptr(), n)
+    pview.msm_begin(sview)                         # in flight on the other context's stream
+    pts.free()                                     # owner frees: must not hand the blocks out again before the device is idle
+    sv.free()
+    junk = bp.FieldElementVector.from_bytes(owner, O.random_scalars(cid, 73, n), n)      # same size class: would reuse sv's block
+    junk_pts = bp.G1Vector.fixed_base(owner, junk)                                       # ... and pts' block
+    assert pview.msm_end() == want
+    owner.synchronize()
+    junk.free(); junk_pts.free()
+    owner.close(); other.close()
+
+
+def test_two_gpus_rccl_and_multi_device_contexts(bp):
+    """Runs only where two GPUs are visible (the driver's multi-GPU box; skipped on the one-GPU pool): bench.py --gpus 2 --strong over
+    the real nccl (= RCCL) backend, and bp_msm_g1_multi over contexts on two DIFFERENT device ordinals, both against the oracle."""
+    import json, os, subprocess, sys
+    if bp.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--strong", "--lg-n", "18", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["verified"] is True and "rehearsal" not in d
+    cid = 0
+    n = 1 << 16
+    ks, ss = O.random_scalars(cid, 81, n), O.random_scalars(cid, 82, n)
+    want = O.g1_mul(cid, O.fr_inner(cid, ks, ss, n), O.generator(cid))
+    ctxs = [bp.Context(cid, 0), bp.Context(cid, 1)]
+    half = n // 2
+    pv, svs = [], []
+    for i, c in enumerate(ctxs):
+        kb, sb = ks[i * half * 32:(i + 1) * half * 32], ss[i * half * 32:(i + 1) * half * 32]
+        pv.append(bp.G1Vector.fixed_base(c, bp.FieldElementVector.from_bytes(c, kb, half)))
+        svs.append(bp.FieldElementVector.from_bytes(c, sb, half))
+    assert bp.msm_multi(ctxs, pv, svs) == want
+    for c in ctxs:
+        c.close()

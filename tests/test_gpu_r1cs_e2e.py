@@ -2,7 +2,7 @@
 every vector / group operation going through the C ABI (commitment MSMs, flattened constraints, l/r polynomials, t(x),
 IPP, the verifier's single MSM), the host doing only what the reference's host does: the transcript and a handful of scalars.
 
-The orchestration (bulletproofs-amcl_amd/r1cs.py) restates `Prover::prove` (/root/reference src/r1cs/prover.rs:323-560) and
+The orchestration (tests/r1cs_twin.py) restates `Prover::prove` (/root/reference src/r1cs/prover.rs:323-560) and
 `Verifier::verify` (src/r1cs/verifier.rs:265-452) for a single-phase constraint system (n2 = 0, A_I2 = A_O2 = S2 = O).
 There are no reference vectors for it (the reference cannot run here), so this is a CONSISTENCY test: honest proofs verify,
 and a proof / statement changed anywhere does not."""
@@ -96,7 +96,7 @@ def run_verify(bp, R1, ctx, gens, cons, n, V, proof, rng):
 
 @pytest.mark.parametrize("name,n,m,nq", [("bls12_381", 13, 3, 20), ("bls12_381", 64, 4, 150), ("bn254", 5, 0, 7), ("bls12_381", 300, 2, 400)])
 def test_r1cs_prove_and_verify(bp, name, n, m, nq):
-    from bulletproofs_amcl_amd import r1cs as R1
+    import r1cs_twin as R1
     ctx = bp.Context(bp.CURVE_IDS[name], 0)
     r = ctx.r
     rng = random.Random(31 * n + m)

@@ -1,0 +1,53 @@
+"""scripts/compare_pins.py (the checker for integration/rust/pin_fixtures.rs output) accepts a pins file synthesised from this
+repository's own assumptions -- the fixtures and pyref -- and flags a line that differs.  CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def synth():
+    import pyref as R
+    lines = []
+    gold = lambda n: json.load(open(os.path.join(ROOT, "tests", "golden", n + ".json")))
+    for cname, c in (("bls12_381", R.BLS12_381), ("bn254", R.BN254)):
+        mb = c.modbytes
+        le = lambda v: (v % c.r).to_bytes(32, "little").hex()
+        lines.append({"item": "fr_to_bytes", "curve": cname, "modbytes": mb, "one": (1).to_bytes(mb, "big").hex(),
+                      "x0102030405060708": (0x0102030405060708).to_bytes(mb, "big").hex()})
+        lines.append({"item": "g1_to_bytes", "curve": cname, "generator": c.g1_to_bytes(c.g).hex(), "identity": c.g1_to_bytes(None).hex(),
+                      "two_g": c.g1_to_bytes(c.add(c.g, c.g)).hex()})
+        lines.append({"item": "fr_from_bytes", "curve": cname, "all_ff": le((1 << (8 * mb)) - 1), "be_one": le(1), "le_one": "?"})
+        g = gold("hash_to_g1")["curves"][cname]
+        for x in g["from_msg_hash"][:3]:
+            lines.append({"item": "from_msg_hash", "curve": cname, "msg": x["msg"], "point": x["point"]})
+        lines.append({"item": "get_generators", "curve": cname, "prefix": "H", "points": g["get_generators"]["H"]})
+        lines.append({"item": "generator", "curve": cname, "G": gold("curves")[cname]["G"], "G_hex": "", "order": ""})
+        t = R.Transcript(b"pin")
+        t.commit_point(c, b"P", c.g)
+        t.commit_scalar(c, b"s", 5)
+        ch = t.challenge_scalar(c, b"c")
+        lines.append({"item": "transcript", "curve": cname, "challenge": ch.to_bytes(32, "little").hex(), "after": t.challenge_bytes(b"after", 32).hex()})
+        w = next(x for x in gold("ipp")[cname] if x["name"] == "test_ipp_n4_hashed_generators")
+        lines.append({"item": "ipp", "curve": cname, "name": w["name"], **{k: w[k] for k in ("L", "R", "L_amcl", "a_out", "b_out", "transcript_after")}})
+    return lines
+
+
+def run(lines, tmp_path, name):
+    f = tmp_path / name
+    f.write_text("\n".join(json.dumps(x) for x in lines))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "compare_pins.py"), str(f)], capture_output=True, text=True, timeout=120)
+
+
+def test_compare_pins_accepts_own_assumptions_and_flags_a_difference(tmp_path):
+    lines = synth()
+    p = run(lines, tmp_path, "ok.jsonl")
+    assert p.returncode == 0 and "0 mismatch(es)" in p.stdout and "MISMATCH" not in p.stdout, p.stdout + p.stderr
+    lines[1]["identity"] = "04" + "00" * 96            # e.g. amcl writing the identity as 04 || 0 || 0
+    lines[-1]["a_out"] = "00" * 32
+    p = run(lines, tmp_path, "bad.jsonl")
+    assert p.returncode == 1 and p.stdout.count("MISMATCH") == 2, p.stdout + p.stderr
+    assert os.path.exists(os.path.join(ROOT, "integration", "rust", "pin_fixtures.rs"))
