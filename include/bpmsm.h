@@ -87,6 +87,7 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_REDUCE_M 2    /* buckets per bucket-reduce thread: a power of two in [1, 16384] */
 #define BP_TUNE_TASK_TARGET 3 /* number of tasks the accumulate kernel aims at: [1024, 2^28] */
 #define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 512 terms */
+#define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 8 (0: 4 when a fold has >= 48 records, else 1) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
 /* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
  * of a small proof; blocks are recycled in stream order).  bp_ctx_trim returns the cached blocks to the driver. */

@@ -1,22 +1,28 @@
 #!/bin/bash
 # Round profiles of the DEFAULT bench command (python3 bench.py ...): kernel-trace stats, then counter passes (each its own
 # run, counters only -- never combined with tracing domains).  Run on the GPU box from the repo root:
-#     scripts/profile_bench.sh r02
+#     scripts/profile_bench.sh r03
 # writes gpurun_out/<tag>_bench_n1_{kernel_stats.csv,under_rocprof.json,pmc_hbm.json,pmc_sq.json}; copy them to profiles/.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out
-args="--steps 10 --warmup 2 --no-cpu-baseline"
+args="--steps 10 --warmup 2 --no-cpu-baseline --no-extras"
+# clocks / power state of THIS box next to the profile (box-to-box spread of the dominant kernel was 11 % in round 2 and could not be
+# attributed): rocm-smi before the run (idle) and right after it
+smi() { { date -u +"%Y-%m-%d %H:%M:%S UTC  $1"; rocm-smi --showclocks --showpower --showperflevel --showtemp 2>&1 | grep -v "^$\|====\|WARNING"; } >> "$out/${tag}_bench_n1_rocm_smi.txt"; }
+rm -f "$out/${tag}_bench_n1_rocm_smi.txt"
+smi "before the kernel-trace run"
 # 1. kernel trace + stats of the default command
 d=$out/prof_${tag}_trace; rm -rf "$d"; mkdir -p "$d"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python3 "$root/bench.py" $args > "$out/${tag}_bench_n1_under_rocprof.json" 2> "$d/stderr.log"
 cp "$(find "$d" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_n1_kernel_stats.csv"
+smi "after the kernel-trace run"
 # 2. counter passes
 pass() {  # name, counters
     local dd=$out/prof_${tag}_$1; rm -rf "$dd"; mkdir -p "$dd"
-    rocprofv3 --pmc $2 --output-format csv -d "$dd" -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-verify > "$dd/stdout.log" 2> "$dd/stderr.log"
+    rocprofv3 --pmc $2 --output-format csv -d "$dd" -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-extras > "$dd/stdout.log" 2> "$dd/stderr.log"
     echo "pass $1 done"
 }
 pass fetch "FETCH_SIZE"

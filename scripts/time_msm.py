@@ -29,7 +29,7 @@ def main():
     if os.environ.get("BP_DEVICE_TAIL"):
         ctx.set_device_tail(True)
     # sweep knobs of THIS script (the library itself reads no tuning variable): TM_TILE / TM_REDUCE_M / TM_TASK_TARGET / TM_SMALL_MSM
-    for var, knob in (("TM_TILE", bp.TUNE_TILE), ("TM_REDUCE_M", bp.TUNE_REDUCE_M), ("TM_TASK_TARGET", bp.TUNE_TASK_TARGET), ("TM_SMALL_MSM", bp.TUNE_SMALL_MSM)):
+    for var, knob in (("TM_TILE", bp.TUNE_TILE), ("TM_REDUCE_M", bp.TUNE_REDUCE_M), ("TM_TASK_TARGET", bp.TUNE_TASK_TARGET), ("TM_SMALL_MSM", bp.TUNE_SMALL_MSM), ("TM_TAIL_CHAINS", bp.TUNE_TAIL_CHAINS)):
         if os.environ.get(var):
             ctx.set_tuning(knob, int(os.environ[var]))
     for lg in lgs:
