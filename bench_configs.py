@@ -60,11 +60,24 @@ def ipp_instance(ctx, n, seed):
     return Gv, Hv, Q, Gf, Hf, a, b, P
 
 
-def time_ipp(ctx, n, seed, oracle=False):
+def time_ipp(ctx, n, seed, oracle=False, tables=True):
     Gv, Hv, Q, Gf, Hf, a, b, P = ipp_instance(ctx, n, seed)
     tc, proof = best_of(lambda: bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b))
     tv, _ = best_of(lambda: bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R))
     res = {"n": n, "create_ms": tc * 1e3, "verify_ms": tv * 1e3, "accepted": True}
+    if tables and 2 * n + 1 > 512:
+        # the same proof with window-multiples tables on the (public, reusable) generators: bp_g1vec_precompute, built once
+        t0 = time.perf_counter()
+        Gv.precompute(16)
+        Hv.precompute(16)
+        ctx.synchronize()
+        t_build = time.perf_counter() - t0
+        tt, proof_t = best_of(lambda: bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b))
+        cw, W, nbytes = Gv.table_info()
+        res["with_tables"] = {"create_ms": tt * 1e3, "same_proof_bytes": bool((proof_t.L, proof_t.R, proof_t.a, proof_t.b) == (proof.L, proof.R, proof.a, proof.b)),
+                              "window_bits": cw, "windows": W, "table_bytes_G_plus_H": 2 * nbytes, "table_build_ms_once_per_generator_set": t_build * 1e3}
+        Gv.drop_table()
+        Hv.drop_table()
     if oracle:
         args = (Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes())
         t0 = time.perf_counter()
@@ -255,6 +268,17 @@ def cfg3_e2e():
     proof = do_prove()
     tp, proof = best_of(do_prove, reps=3)
     tv, ok = best_of(lambda: do_verify(proof), reps=3)
+    # with window-multiples tables on G and H (public parameters: built once, reused by every proof)
+    t0 = time.perf_counter()
+    gens.G.precompute(16)
+    gens.H.precompute(16)
+    ctx.synchronize()
+    t_tables = time.perf_counter() - t0
+    tpt, proof_t = best_of(do_prove, reps=3)
+    tables = {"prove_ms": tpt * 1e3, "same_proof_bytes": bool(proof_t == proof), "window_bits": gens.G.table_info()[0], "table_bytes_G_plus_H": 2 * gens.G.table_info()[2],
+              "table_build_ms_once_per_generator_set": t_tables * 1e3}
+    gens.G.drop_table()
+    gens.H.drop_table()
     tpp, pyproof = best_of(py_prove, reps=2)
     tpv, pyok = best_of(lambda: R1.verify(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), V, pyproof), reps=2)
     ipp = pyproof["ipp"]
@@ -266,7 +290,7 @@ def cfg3_e2e():
     out = {"config": "cfg3 end to end: 1024 chained 32-bit bound checks, BLS12-381, bp_r1cs_prove + bp_r1cs_verify (host orchestration in C++ "
                      "inside libbpmsm.so over its own C ABI)",
            "gates": n, "constraints": nq, "committed": m, "terms": len(terms),
-           "prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "accepted": bool(ok), "tampered_rejected": bool(rejected),
+           "prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "accepted": bool(ok), "tampered_rejected": bool(rejected), "with_tables": tables,
            "python_mirror_prove_ms": tpp * 1e3, "python_mirror_verify_ms": tpv * 1e3, "python_mirror_accepts": bool(pyok),
            "library_and_python_proofs_identical": bool(same),
            "of_which_transcript_of_3072_commitments_ms": t_tr * 1e3,

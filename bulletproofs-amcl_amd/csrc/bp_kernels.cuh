@@ -436,6 +436,10 @@ __global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* 
             xyzz_lazy_add_aff(acc, p);
         }
         if (acc.inf) continue;
+        // (Software prefetch of the next row -- plain C++ and, because the compiler's register reuse forced an early s_waitcnt, as
+        // hand-issued inline-asm loads whose only wait sits at the top of the next iteration -- was measured again in round 3: 2.24-2.30
+        // against 2.24-2.25 ms.  The second resident wave already covers the gather; the 8.6 % "waiting on memory" of the SQ
+        // counters is time the other wave spends issuing.)
         while (s < e) {
             const uint32_t code = idx[s];
             const Aff<C> p = aff_unpack(pts[code & 0x7fffffffu]);

@@ -16,7 +16,12 @@ rm -f "$out/${tag}_bench_n1_rocm_smi.txt"
 smi "before the kernel-trace run"
 # 1. kernel trace + stats of the default command
 d=$out/prof_${tag}_trace; rm -rf "$d"; mkdir -p "$d"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python3 "$root/bench.py" $args > "$out/${tag}_bench_n1_under_rocprof.json" 2> "$d/stderr.log"
+# sample the clocks WHILE the bench runs (after it, sclk has already dropped): a background loop on this shell, stopped by its PID
+( while true; do { date -u +"%H:%M:%S.%N UTC  during the kernel-trace run"; rocm-smi --showclocks --showpower 2>&1 | grep "sclk\|mclk\|Power"; } >> "$out/${tag}_bench_n1_rocm_smi.txt"; sleep 0.3; done ) &
+sampler=$!
+rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python3 "$root/bench.py" $args --steps 60 > "$out/${tag}_bench_n1_under_rocprof.json" 2> "$d/stderr.log"
+kill $sampler 2>/dev/null || true
+wait $sampler 2>/dev/null || true
 cp "$(find "$d" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_n1_kernel_stats.csv"
 smi "after the kernel-trace run"
 # 2. counter passes
