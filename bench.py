@@ -3,7 +3,7 @@
 
 A "step" is one MSM  sum_i s_i P_i  over synthetic inputs already resident in HBM: random points (k_i * G, generated on
 the device) and uniformly random scalars.  With N > 1 ranks (one process per GPU) the index range is sharded: every rank
-runs the bucket pipeline on its own slice, the per-window bucket sums (16 records x 192 B + a geometry header per rank) are
+runs the bucket pipeline on its own slice, its tail records (208 x 192 B at 2^20 points: per window one weighted sum + one record per bit plane; + a geometry header) are
 all-gathered over RCCL, and the MSM over all points is finished on every rank.
   default ("scaling": "weak")   2^lg-n points PER GPU (2^20: the headline configuration, BASELINE config 2)
   --strong ("scaling": "strong") 2^lg-n points IN TOTAL, split by index range (default 2^22: BASELINE config 4, 2^19 per GPU at 8)

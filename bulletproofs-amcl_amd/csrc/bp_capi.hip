@@ -386,7 +386,7 @@ struct Impl {
     static void fold_parallel(bp_ctx* ctx, int nfolds, const XyzzPacked<C>* const* rec, size_t sets, int nrec, const uint16_t* const* pos, uint8_t* const* out_le) {
         using Jac = typename host::Tail<C>::Jac;
         const host::Tail<C>& tl = tail();
-        int chains = ctx && ctx->tail_chains > 0 ? ctx->tail_chains : ((size_t)nrec * sets >= 48 ? 4 : 1);
+        int chains = ctx && ctx->tail_chains > 0 ? ctx->tail_chains : ((size_t)nrec * sets >= 400 ? 8 : (size_t)nrec * sets >= 48 ? 4 : 1);     // 8: the record sets of several shards
         if (chains > host::Tail<C>::kMaxChains) chains = host::Tail<C>::kMaxChains;
         if (!ctx) chains = 1;
         Jac parts[2 * host::Tail<C>::kMaxChains];

@@ -295,13 +295,16 @@ public:
         int cur = -1, seen = 0;
         for (int p = top; p >= 0; p--) {
             for (int r = head[p]; r >= 0; r = next[r]) {
-                bool any = false;
-                for (size_t s = 0; s < sets && !any; s++) any = !is_identity_record(rec[s * (size_t)nrec + r]);
-                if (!any) continue;
-                if ((seen++ % chains) != k) continue;          // dealt round-robin among the chains (identity records are not dealt)
-                if (cur >= 0) for (int i = 0; i < cur - p; i++) dbl(acc);
-                cur = p;
-                for (size_t s = 0; s < sets; s++) add(acc, from_record(rec[s * (size_t)nrec + r]));
+                // (record, set) pairs are dealt round-robin among the chains (identity records are not dealt): with N shards' record
+                // sets the additions -- N per bit position -- spread over the chains like those of a single set
+                for (size_t s = 0; s < sets; s++) {
+                    const XyzzPacked<C>& rs = rec[s * (size_t)nrec + r];
+                    if (is_identity_record(rs)) continue;
+                    if ((seen++ % chains) != k) continue;
+                    if (cur >= 0) for (int i = 0; i < cur - p; i++) dbl(acc);
+                    cur = p;
+                    add(acc, from_record(rs));
+                }
             }
         }
         for (int i = 0; i < cur; i++) dbl(acc);

@@ -214,9 +214,10 @@ int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, s
  * off[W], and the recoding bias (window w of k + bias, minus 2^(cw-1) - 1, is the signed digit of window w).  Any output
  * pointer may be NULL. */
 int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32);
-/* A record block holds nrec records (one per window in this version; the host fold accepts any list) and its header; record r
- * carries weight 2^pos[r]:  result = sum_r 2^pos[r] * record[r].  nrec = bp_msm_window_records() - 1; pos_out needs room for
- * 256 entries. */
+/* A record block holds nrec records and its header; record r carries weight 2^pos[r]:  result = sum_r 2^pos[r] * record[r].
+ * Since round 3 a window contributes one record for its plain weighted sum plus one per bit of the reduce-thread index (bit planes:
+ * 13 per window at n = 2^20); the single-launch path for n <= 512 -- taken only when no window width is fixed -- has one per window.
+ * nrec = bp_msm_window_records() - 1; pos_out needs room for 4096 entries. */
 int bp_msm_record_positions(int curve_id, size_t n, int window_bits, int* nrec_out, uint16_t* pos_out);
 /* Record-block helpers for hosts that build or check blocks themselves (tests, aggregators): an affine point as a window
  * record, and the header record of the geometry above.  Host arithmetic. */
@@ -226,7 +227,11 @@ int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_o
  * src/ipp.rs:251-253, has neither): shard i = (points[i], scalars[i]) is resident with ctxs[i] -- contexts on different
  * devices of the node, or several on one device.  All shards run concurrently with one common window width; each device
  * copies its W window sums (W x 192 B) to pinned host memory and the caller's thread folds the n_shards sets.  That gather
- * IS the "reduce" of the partial sums: n_shards x 3 KiB, latency-bound; point addition is not an RCCL op. */
+ * IS the "reduce" of the partial sums: n_shards x ~40 KiB of tail records, latency-bound; point addition is not an RCCL op
+ * (SURVEY F9).  NOTE (SURVEY 8b asked for an in-library RCCL communicator): this entry point deliberately stages the records through
+ * PINNED HOST MEMORY -- one D2H copy per device -- because the fold that consumes them runs on the host anyway; the RCCL path
+ * (all_gather of the same record blocks in HBM, bp_msm_g1_windows + bp_msm_g1_finish) is what a one-process-per-GPU host uses
+ * (bench.py, bulletproofs-amcl_amd/sharding.py). */
 int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp_frvec* const* scalars, size_t n_shards, uint8_t* out_le);
 
 /* Timing of the last bp_msm_* call on this context, measured with HIP events on the context's stream.
