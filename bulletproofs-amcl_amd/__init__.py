@@ -160,6 +160,7 @@ SYMBOLS = {
     "bp_ipp_state_finish": (_I, [_P, _U8P, _U8P]),
     "bp_ipp_state_free": (_I, [_P]),
     "bp_ipp_create": (_I, [_P, _P, _U8P, _P, _P, _P, _P, _P, _P, _U8P, _U8P, ctypes.POINTER(ctypes.c_size_t), _U8P, _U8P]),
+    "bp_ipp_create_multi": (_I, [_P, _SZ, _P, _U8P, _P, _P, _P, _P, _U8P, _U8P, _SZ, _U8P, _U8P, ctypes.POINTER(ctypes.c_size_t), _U8P, _U8P]),
     "bp_ipp_verify": (_I, [_P, _P, _SZ, _P, _P, _U8P, _U8P, _P, _P, _U8P, _U8P, _U8P, _U8P, _SZ]),
     "bp_ipp_verify_batch": (_I, [_P, _SZ, _SZ, _P, _P, _P, _P, _P, _SZ, _U8P]),
     "bp_ipp_verification_scalars": (_I, [_I, _P, _U8P, _U8P, _SZ, _SZ, _U8P, _U8P, _U8P]),
@@ -704,6 +705,23 @@ class IPP:
                                    ctypes.byref(lg_n), a, b), "bp_ipp_create")
         k = lg_n.value
         return InnerProductArgumentProof(L.raw[: k * ctx.point_bytes], R.raw[: k * ctx.point_bytes], a.raw, b.raw, k)
+
+    @staticmethod
+    def create_ipp_multi(ctxs, transcript, Q_le, G_factors, H_factors, G_vecs, H_vecs, a_le, b_le):
+        """create_ipp with the generators sharded by index range over several contexts (bp_ipp_create_multi): shard i of every list
+        lives with ctxs[i]; a_le / b_le are the n x 32-byte host scalars.  Same proof bytes as create_ipp."""
+        k = len(ctxs)
+        n = sum(len(g) for g in G_vecs)
+        A = lambda xs: (ctypes.c_void_p * k)(*[x.h for x in xs])
+        pb = ctxs[0].point_bytes
+        lg = max(1, n.bit_length())
+        L, R = ctypes.create_string_buffer(lg * pb), ctypes.create_string_buffer(lg * pb)
+        a, b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        lg_n = ctypes.c_size_t(0)
+        _check(lib().bp_ipp_create_multi(A(ctxs), k, transcript.h, bytes(Q_le), A(G_factors), A(H_factors), A(G_vecs), A(H_vecs), bytes(a_le), bytes(b_le), n,
+                                         L, R, ctypes.byref(lg_n), a, b), "bp_ipp_create_multi")
+        kk = lg_n.value
+        return InnerProductArgumentProof(L.raw[: kk * pb], R.raw[: kk * pb], a.raw, b.raw, kk)
 
     @staticmethod
     def verify_ipp(ctx, n, transcript, G_factors, H_factors, P_le, Q_le, G, H, a_le32, b_le32, L_le, R_le):

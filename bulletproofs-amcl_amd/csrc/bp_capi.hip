@@ -386,7 +386,10 @@ struct Impl {
     static void fold_parallel(bp_ctx* ctx, int nfolds, const XyzzPacked<C>* const* rec, size_t sets, int nrec, const uint16_t* const* pos, uint8_t* const* out_le) {
         using Jac = typename host::Tail<C>::Jac;
         const host::Tail<C>& tl = tail();
-        int chains = ctx && ctx->tail_chains > 0 ? ctx->tail_chains : ((size_t)nrec * sets >= 400 ? 8 : (size_t)nrec * sets >= 48 ? 4 : 1);     // 8: the record sets of several shards
+        // 4 chains for one set of bit-plane records; 8 / 16 when the sets of several shards are folded together (N x 208 additions:
+        // each chain still walks all ~255 doublings, so more chains only thin out the additions)
+        const size_t pairs = (size_t)nrec * sets;
+        int chains = ctx && ctx->tail_chains > 0 ? ctx->tail_chains : (pairs >= 1200 ? 16 : pairs >= 400 ? 8 : pairs >= 48 ? 4 : 1);
         if (chains > host::Tail<C>::kMaxChains) chains = host::Tail<C>::kMaxChains;
         if (!ctx) chains = 1;
         Jac parts[2 * host::Tail<C>::kMaxChains];
@@ -677,6 +680,41 @@ int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, cons
     DISPATCH(ctx, I::msm2(ctx, points, scalars1, scalars2, n, out1_le, out2_le, nnz, tb));
 }
 
+// ---- building blocks of the sharded inner-product argument (bp_capi_ipp.hip: bp_ipp_create_multi) ----
+// The window width a paired MSM of n terms (nnz non-zero per set) picks on its own: the shards then all run with it FIXED.
+int bp_internal_pair_width(bp_ctx* ctx, size_t n, size_t nnz) {
+    MsmGeom g;
+    const int bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
+    if (msm_geom(g, bits, n, ctx->c_override, 2, nnz, &ctx->tuning)) return 0;
+    return g.c;
+}
+// Device stage of a paired MSM with the window width fixed to c (or the table's width): the 2 x (nrec / 2) tail records are
+// copied to ctx->host_pinned asynchronously; the caller synchronises ctx->stream before reading them.
+template <class C>
+static int msm2_begin_impl(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, int c, size_t nnz, const bp_g1table* tb, int* nrec_out, uint16_t* rpos_out) {
+    const int saved = ctx->c_override;
+    ctx->c_override = c;
+    MsmGeom g;
+    int rc = Impl<C>::msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz, tb);
+    ctx->c_override = saved;
+    if (rc) return rc;
+    if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * Impl<C>::kXyzzBytes))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * Impl<C>::kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+    *nrec_out = g.nrec;
+    memcpy(rpos_out, g.rpos, (size_t)g.nrec * sizeof(uint16_t));
+    return BP_OK;
+}
+int bp_internal_msm2_begin(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, int c, size_t nnz, const bp_g1table* tb, int* nrec_out, uint16_t* rpos_out) {
+    if (ctx->curve == BP_CURVE_BLS12_381) return msm2_begin_impl<Bls381>(ctx, pts, sc1, sc2, n, c, nnz, tb, nrec_out, rpos_out);
+    return msm2_begin_impl<Bn254>(ctx, pts, sc1, sc2, n, c, nnz, tb, nrec_out, rpos_out);
+}
+// out_le[f] = sum over the `sets` record sets of fold f (f < nfolds <= 2); rec[f] holds sets x nrec records, set-major
+int bp_internal_fold_sets(bp_ctx* ctx, int nfolds, const void* const* rec, size_t sets, int nrec, const uint16_t* const* pos, uint8_t* const* out_le) {
+    if (ctx->curve == BP_CURVE_BLS12_381) Impl<Bls381>::fold_parallel(ctx, nfolds, (const XyzzPacked<Bls381>* const*)rec, sets, nrec, pos, out_le);
+    else Impl<Bn254>::fold_parallel(ctx, nfolds, (const XyzzPacked<Bn254>* const*)rec, sets, nrec, pos, out_le);
+    return BP_OK;
+}
+
 // Window-multiples table of n resident points (bp_g1vec_precompute): allocated from the context's pool, built on its stream.
 int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp_g1table** out) {
     *out = nullptr;
@@ -879,7 +917,7 @@ int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
         if (value != 0 && (value < 1024 || value > (1L << 28))) return BP_ERR_ARG;
         ctx->tuning.task_target = (uint64_t)value;
         return BP_OK;
-    case BP_TUNE_TAIL_CHAINS:   // independent Horner walks of the host tail (helper threads): 1 .. 8
+    case BP_TUNE_TAIL_CHAINS:   // independent Horner walks of the host tail (helper threads): 1 .. 16
         if (value > host::Tail<Bls381>::kMaxChains) return BP_ERR_ARG;
         ctx->tail_chains = (int)value;
         return BP_OK;

@@ -152,7 +152,7 @@ struct Ipp {
         if (!st->fold_generators) {
             size_t m = 2 * st->n0 + 1;
             hipLaunchKernelGGL(k_ipp_round_scalars<C>, dim3(blocks_for(st->n0)), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG,
-                               (const ScalarWords*)st->cH, cLR, st->n0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
+                               (const ScalarWords*)st->cH, cLR, st->n0, (size_t)0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR, 1);
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
             return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1, st->table);   // both sums in one pipeline pass
@@ -175,7 +175,7 @@ struct Ipp {
         Fe<F> u = fr_from_le<F>(u_le), ui = fr_from_le<F>(uinv_le);
         if (!st->fold_generators) {
             hipLaunchKernelGGL(k_ipp_fold_scalars<C>, dim3(blocks_for(st->n0)), dim3(kBlock), 0, ctx->stream, (ScalarWords*)st->a, (ScalarWords*)st->b,
-                               (ScalarWords*)st->cG, (ScalarWords*)st->cH, fr_mont_words<F>(u), fr_mont_words<F>(ui), st->n0, st->n);
+                               (ScalarWords*)st->cG, (ScalarWords*)st->cH, fr_mont_words<F>(u), fr_mont_words<F>(ui), st->n0, (size_t)0, st->n);
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp fold scalars");
             st->n = h;
@@ -524,6 +524,150 @@ static int commit_pairs_impl(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_
     HIPCHK(hipGetLastError());
     return BP_OK;
 }
+
+// ---- IPP::create_ipp with the generators sharded by index range over several contexts (second sentence) ----------
+// Shard s holds G[k0_s .. k0_s + n_s), H[...], their factors and -- because the generators are never folded (bp_ipp.cuh) -- only the
+// matching slices of the coefficient vectors c_G, c_H; the short vectors a, b are replicated and folded on every shard.  A round is:
+// every shard computes c_L / c_R (redundantly: two inner products of the current a, b), its slice of the L / R scalars and the
+// device stage of its paired MSM (asynchronously, one common window width); the host then folds the N record sets of L and of R
+// (the "all-gather of the L, R partials" of the survey, through pinned host memory as in bp_msm_g1_multi), runs the transcript and
+// hands u, u^-1 back to every shard's fold kernel.  Same L, R, a, b as the single-device prover, bit for bit.
+namespace {
+struct IppShard {
+    bp_ctx* ctx = nullptr;
+    size_t k0 = 0, nloc = 0;
+    PoolBlock a, b, cG, cH, sL, sR, pall, cLR, partial, raw;
+    bp_g1table* table = nullptr;
+    ~IppShard() { if (table) bp_internal_table_free(table); }
+};
+
+template <class C>
+int ipp_create_multi(bp_ctx* const* ctxs, size_t N, Transcript& t, const uint8_t* Q_le, const bp_frvec* const* Gf, const bp_frvec* const* Hf,
+                     const bp_g1vec* const* G, const bp_g1vec* const* H, const uint8_t* a_le, const uint8_t* b_le, size_t n, uint8_t* L_out,
+                     uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out, uint8_t* b_out) {
+    using F = typename C::Fr;
+    using I = Ipp<C>;
+    constexpr size_t kPt = sizeof(AffPacked<C>);
+    constexpr int kFb = 4 * C::Fp::NW;
+    std::vector<IppShard> sh(N);
+    size_t k0 = 0, nmax = 0;
+    bool tables = true;
+    for (size_t s = 0; s < N; s++) {
+        sh[s].ctx = ctxs[s]; sh[s].k0 = k0; sh[s].nloc = G[s]->n;
+        k0 += G[s]->n;
+        if (G[s]->n > nmax) nmax = G[s]->n;
+        tables = tables && G[s]->table && H[s]->table && G[s]->table->c == G[0]->table->c && H[s]->table->c == G[0]->table->c;
+    }
+    int rc;
+    // canonical scalars only (as bp_frvec_upload checks): validate a, b once, on the first shard
+    {
+        bp_frvec *ta = nullptr, *tb = nullptr;
+        rc = bp_frvec_upload(ctxs[0], a_le, n, &ta);
+        if (!rc) rc = bp_frvec_upload(ctxs[0], b_le, n, &tb);
+        bp_frvec_free(ta); bp_frvec_free(tb);
+        if (rc) return rc;
+    }
+    const uint8_t zero_pt[2 * kFb] = {0};
+    for (size_t s = 0; s < N; s++) {
+        IppShard& x = sh[s];
+        bp_ctx* ctx = x.ctx;
+        if ((rc = bp_internal_set_device(ctx))) return rc;
+        const size_t nl = x.nloc, m = 2 * nl + 1;
+        if (!x.a.alloc(ctx, n * 32) || !x.b.alloc(ctx, n * 32) || !x.cG.alloc(ctx, nl * 32) || !x.cH.alloc(ctx, nl * 32) || !x.sL.alloc(ctx, m * 32) ||
+            !x.sR.alloc(ctx, m * 32) || !x.pall.alloc(ctx, m * kPt) || !x.cLR.alloc(ctx, 64) || !x.partial.alloc(ctx, (kInnerBlocks + 1) * 32) || !x.raw.alloc(ctx, kPt))
+            return BP_ERR_DEVICE;
+        hipStream_t st = ctx->stream;
+        if ((rc = ctx->flags.reserve(ctx, 64))) return rc;
+        uint32_t host_flag = 0;
+        HIPCHK(hipMemsetAsync(ctx->flags.p, 0, 4, st));
+        HIPCHK(hipMemcpyAsync(x.a.p, a_le, n * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x.b.p, b_le, n * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x.cG.p, Gf[s]->d, nl * 32, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(x.cH.p, Hf[s]->d, nl * 32, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(x.pall.p, G[s]->d, nl * kPt, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync((uint8_t*)x.pall.p + nl * kPt, H[s]->d, nl * kPt, hipMemcpyDeviceToDevice, st));
+        // last term: Q on the first shard (validated like any point from outside), the identity elsewhere
+        HIPCHK(hipMemcpyAsync(x.raw.p, s == 0 ? Q_le : zero_pt, 2 * kFb, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)x.raw.p, (size_t)1, (AffPacked<C>*)x.pall.p + 2 * nl, (uint32_t*)ctx->flags.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&host_flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));               // a_le / b_le / Q_le are borrowed host buffers
+        if (host_flag) return BP_ERR_ARG;
+        if (tables && (rc = bp_internal_table_concat(ctx, G[s], 0, H[s], 0, nl, s == 0 ? Q_le : zero_pt, &x.table))) return rc;
+        if (tables && !x.table) tables = false;
+    }
+    if (!tables) for (auto& x : sh) if (x.table) { bp_internal_table_free(x.table); x.table = nullptr; }
+    const int c = tables ? 0 : bp_internal_pair_width(ctxs[0], 2 * nmax + 1, nmax + 1);
+    if (!tables && c <= 0) return BP_ERR_ARG;
+
+    I::ipp_domain_sep(t, n);
+    std::vector<uint16_t> rpos(kMaxRecords);
+    std::vector<XyzzPacked<C>> recL, recR;
+    size_t nj = n, k = 0;
+    while (nj != 1) {
+        const size_t h = nj / 2;
+        int nrec = 0;
+        for (size_t s = 0; s < N; s++) {                       // queue every shard's round; nothing waits here
+            IppShard& x = sh[s];
+            bp_ctx* ctx = x.ctx;
+            if ((rc = bp_internal_set_device(ctx))) return rc;
+            auto* a = (ScalarWords*)x.a.p; auto* b = (ScalarWords*)x.b.p;
+            unsigned g = blocks_for(h);
+            if (g > kInnerBlocks / 2) g = kInnerBlocks / 2;
+            if (g == 0) g = 1;
+            hipLaunchKernelGGL(k_fr_inner2<C>, dim3(g, 2), dim3(kBlock), 0, ctx->stream, a, b + h, a + h, b, h, (ScalarWords*)x.partial.p);
+            hipLaunchKernelGGL(k_fr_inner2_final<C>, dim3(2), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)x.partial.p, g, (ScalarWords*)x.cLR.p);
+            hipLaunchKernelGGL(k_ipp_round_scalars<C>, dim3(blocks_for(x.nloc)), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)x.cG.p,
+                               (const ScalarWords*)x.cH.p, (const ScalarWords*)x.cLR.p, x.nloc, x.k0, nj, (ScalarWords*)x.sL.p, (ScalarWords*)x.sR.p, s == 0 ? 1 : 0);
+            HIPCHK(hipGetLastError());
+            int nr = 0;
+            if ((rc = bp_internal_msm2_begin(ctx, x.pall.p, x.sL.p, x.sR.p, 2 * x.nloc + 1, c, x.nloc + 1, x.table, &nr, rpos.data()))) return rc;
+            if (s && nr != nrec) return BP_ERR_DEVICE;            // one geometry for all shards
+            nrec = nr;
+        }
+        const int R1 = nrec / 2;
+        recL.resize(N * (size_t)R1);
+        recR.resize(N * (size_t)R1);
+        for (size_t s = 0; s < N; s++) {
+            if ((rc = bp_internal_set_device(sh[s].ctx))) return rc;
+            HIPCHK(hipStreamSynchronize(sh[s].ctx->stream));
+            const XyzzPacked<C>* r = (const XyzzPacked<C>*)sh[s].ctx->host_pinned;
+            memcpy(&recL[s * (size_t)R1], r, (size_t)R1 * sizeof(XyzzPacked<C>));
+            memcpy(&recR[s * (size_t)R1], r + R1, (size_t)R1 * sizeof(XyzzPacked<C>));
+        }
+        uint8_t* L = L_out + k * 2 * kFb;
+        uint8_t* R = R_out + k * 2 * kFb;
+        const void* recs[2] = {recL.data(), recR.data()};
+        const uint16_t* poss[2] = {rpos.data(), rpos.data() + R1};
+        uint8_t* outs[2] = {L, R};
+        if ((rc = bp_internal_fold_sets(ctxs[0], 2, recs, N, R1, poss, outs))) return rc;
+        I::commit_point(t, "L", L);
+        I::commit_point(t, "R", R);
+        Fe<F> u = I::challenge_scalar(t, "u");
+        Fe<F> ui = fr_inv_fast<F>(u);
+        for (size_t s = 0; s < N; s++) {
+            IppShard& x = sh[s];
+            if ((rc = bp_internal_set_device(x.ctx))) return rc;
+            const size_t span = x.nloc > h ? x.nloc : h;
+            hipLaunchKernelGGL(k_ipp_fold_scalars<C>, dim3(blocks_for(span)), dim3(kBlock), 0, x.ctx->stream, (ScalarWords*)x.a.p, (ScalarWords*)x.b.p,
+                               (ScalarWords*)x.cG.p, (ScalarWords*)x.cH.p, fr_mont_words<F>(u), fr_mont_words<F>(ui), x.nloc, x.k0, nj);
+            HIPCHK(hipGetLastError());
+        }
+        nj = h;
+        k++;
+    }
+    if (lg_n_out) *lg_n_out = k;
+    if ((rc = bp_internal_set_device(ctxs[0]))) return rc;
+    HIPCHK(hipMemcpyAsync(a_out, sh[0].a.p, 32, hipMemcpyDeviceToHost, ctxs[0]->stream));
+    HIPCHK(hipMemcpyAsync(b_out, sh[0].b.p, 32, hipMemcpyDeviceToHost, ctxs[0]->stream));
+    for (size_t s = 0; s < N; s++) {                           // the shards' blocks return to their pools: nothing may be in flight
+        if ((rc = bp_internal_set_device(ctxs[s]))) return rc;
+        HIPCHK(hipStreamSynchronize(ctxs[s]->stream));
+    }
+    return BP_OK;
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -924,6 +1068,31 @@ int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_f
     else rc = Ipp<Bn254>::create(st, t->t, L_out, R_out, lg_n_out, a_out_le32, b_out_le32);
     bp_ipp_state_free(st);
     return rc;
+}
+
+int bp_ipp_create_multi(bp_ctx* const* ctxs, size_t n_shards, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* const* G_factors,
+                        const bp_frvec* const* H_factors, const bp_g1vec* const* G, const bp_g1vec* const* H, const uint8_t* a_le32,
+                        const uint8_t* b_le32, size_t n, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out_le32, uint8_t* b_out_le32) {
+    if (!ctxs || n_shards == 0 || n_shards > 64 || !t || !Q_le || !G_factors || !H_factors || !G || !H || !a_le32 || !b_le32 || !a_out_le32 || !b_out_le32)
+        return BP_ERR_ARG;
+    if (n == 0 || (n & (n - 1))) return BP_ERR_ARG;                                             // assert!(n.is_power_of_two())  ipp.rs:48
+    if (n > 1 && (!L_out || !R_out)) return BP_ERR_ARG;
+    size_t total = 0;
+    for (size_t s = 0; s < n_shards; s++) {
+        if (!ctxs[s] || !G[s] || !H[s] || !G_factors[s] || !H_factors[s] || ctxs[s]->curve != ctxs[0]->curve) return BP_ERR_ARG;
+        for (size_t j = 0; j < s; j++) if (ctxs[j] == ctxs[s]) return BP_ERR_ARG;              // one shard per context
+        if (G[s]->n == 0 || H[s]->n != G[s]->n || G_factors[s]->n != G[s]->n || H_factors[s]->n != G[s]->n) return BP_ERR_ARG;   // ipp.rs:51-55
+        total += G[s]->n;
+    }
+    if (total != n) return BP_ERR_ARG;
+    try {
+        if (ctxs[0]->curve == BP_CURVE_BLS12_381)
+            return ipp_create_multi<Bls381>(ctxs, n_shards, t->t, Q_le, G_factors, H_factors, G, H, a_le32, b_le32, n, L_out, R_out, lg_n_out, a_out_le32, b_out_le32);
+        return ipp_create_multi<Bn254>(ctxs, n_shards, t->t, Q_le, G_factors, H_factors, G, H, a_le32, b_le32, n, L_out, R_out, lg_n_out, a_out_le32, b_out_le32);
+    } catch (...) {
+        for (size_t s = 0; s < n_shards; s++) { (void)bp_internal_set_device(ctxs[s]); (void)hipStreamSynchronize(ctxs[s]->stream); }
+        return BP_ERR_DEVICE;
+    }
 }
 
 int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_factors, const bp_frvec* H_factors, const uint8_t* P_le,

@@ -208,7 +208,7 @@ private:
     }
 
 public:
-    static constexpr int kMaxChains = 8;
+    static constexpr int kMaxChains = 16;
     Tail() {
         // k = 2^(128 N - 30 NL) mod p, plain integer
         uint64_t t[N] = {};

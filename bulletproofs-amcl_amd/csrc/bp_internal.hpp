@@ -154,7 +154,7 @@ struct HostPool {
     int pending = 0;
     uint64_t epoch = 0;
     bool quit = false;
-    static constexpr int kMaxHelpers = 7;
+    static constexpr int kMaxHelpers = 15;
     void ensure(int helpers) {
         if (helpers > kMaxHelpers) helpers = kMaxHelpers;
         while ((int)th.size() < helpers) {
@@ -349,3 +349,8 @@ extern "C" int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling);
 int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
                      size_t nnz, const bp_g1table* tb = nullptr);
 int bp_internal_set_device(const bp_ctx* ctx);
+// building blocks of the sharded inner-product argument (bp_capi.hip)
+int bp_internal_pair_width(bp_ctx* ctx, size_t n, size_t nnz);
+int bp_internal_msm2_begin(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, int c, size_t nnz, const bp_g1table* tb, int* nrec_out,
+                           uint16_t* rpos_out);
+int bp_internal_fold_sets(bp_ctx* ctx, int nfolds, const void* const* rec, size_t sets, int nrec, const uint16_t* const* pos, uint8_t* const* out_le);

@@ -461,46 +461,51 @@ __global__ void __launch_bounds__(kBlock) k_ipp_fold(AffPacked<C>* __restrict__ 
 //   R:  G_k, pos <  h: a[h + pos] cG_k     H_k, pos >= h: b[pos - h] cH_k     Q: c_R
 // and the per-round "fold" is four Fr multiplications per generator instead of a 255-step double-scalar multiplication
 // (the reference's dominant cost, and on a GPU a ~10 ms serial chain per round).  Identical L, R, a, b.
+// Sharded form (bp_ipp_create_multi): a shard holds the generators k0 .. k0 + nloc - 1 of the n0 originals (cG, cH, sL, sR are
+// its slices, indexed locally; a, b are full replicated copies) and, if with_q, the point Q as its last term.  One device: k0 = 0,
+// nloc = n0, with_q = 1.
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_ipp_round_scalars(const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b,
                                                               const ScalarWords* __restrict__ cG, const ScalarWords* __restrict__ cH,
-                                                              const ScalarWords* __restrict__ cLR, size_t n0, size_t nj,
-                                                              ScalarWords* __restrict__ sL, ScalarWords* __restrict__ sR) {
+                                                              const ScalarWords* __restrict__ cLR, size_t nloc, size_t k0, size_t nj,
+                                                              ScalarWords* __restrict__ sL, ScalarWords* __restrict__ sR, int with_q) {
     using F = typename C::Fr;
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n0) {
-        size_t h = nj / 2, pos = k & (nj - 1);
-        ScalarWords zero;
-        for (int i = 0; i < 8; i++) zero.w[i] = 0;
+    ScalarWords zero;
+    for (int i = 0; i < 8; i++) zero.w[i] = 0;
+    if (k < nloc) {
+        size_t h = nj / 2, pos = (k0 + k) & (nj - 1);
         // canonical * canonical / R, then * R^2 / R  ->  canonical product
         if (pos >= h) {
             fr_store<F>(sL, k, fe_to_mont<F>(fe_mul(fr_load<F>(a, pos - h), fr_load<F>(cG, k))));
             sR[k] = zero;
-            sL[n0 + k] = zero;
-            fr_store<F>(sR, n0 + k, fe_to_mont<F>(fe_mul(fr_load<F>(b, pos - h), fr_load<F>(cH, k))));
+            sL[nloc + k] = zero;
+            fr_store<F>(sR, nloc + k, fe_to_mont<F>(fe_mul(fr_load<F>(b, pos - h), fr_load<F>(cH, k))));
         } else {
             sL[k] = zero;
             fr_store<F>(sR, k, fe_to_mont<F>(fe_mul(fr_load<F>(a, h + pos), fr_load<F>(cG, k))));
-            fr_store<F>(sL, n0 + k, fe_to_mont<F>(fe_mul(fr_load<F>(b, h + pos), fr_load<F>(cH, k))));
-            sR[n0 + k] = zero;
+            fr_store<F>(sL, nloc + k, fe_to_mont<F>(fe_mul(fr_load<F>(b, h + pos), fr_load<F>(cH, k))));
+            sR[nloc + k] = zero;
         }
     }
-    if (k == 0) { sL[2 * n0] = cLR[0]; sR[2 * n0] = cLR[1]; }
+    if (k == 0) { sL[2 * nloc] = with_q ? cLR[0] : zero; sR[2 * nloc] = with_q ? cLR[1] : zero; }
 }
 
 // cG_k *= (pos < h ? u^-1 : u); cH_k *= (pos < h ? u : u^-1); a, b folded (src/ipp.rs:116-129, 182-187).
+// grid covers max(nloc, nj / 2) threads: the coefficient slice and the (replicated) a, b are independent jobs.
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_ipp_fold_scalars(ScalarWords* __restrict__ a, ScalarWords* __restrict__ b, ScalarWords* __restrict__ cG,
-                                                             ScalarWords* __restrict__ cH, ScalarWords u_mont, ScalarWords uinv_mont, size_t n0,
-                                                             size_t nj) {
+                                                             ScalarWords* __restrict__ cH, ScalarWords u_mont, ScalarWords uinv_mont, size_t nloc,
+                                                             size_t k0, size_t nj) {
     using F = typename C::Fr;
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n0) return;
     Fe<F> u = fe_unpack_words<F>(u_mont.w), ui = fe_unpack_words<F>(uinv_mont.w);
-    size_t h = nj / 2, pos = k & (nj - 1);
-    bool left = pos < h;
-    fr_store<F>(cG, k, fe_mul(fr_load<F>(cG, k), left ? ui : u));
-    fr_store<F>(cH, k, fe_mul(fr_load<F>(cH, k), left ? u : ui));
+    size_t h = nj / 2;
+    if (k < nloc) {
+        bool left = ((k0 + k) & (nj - 1)) < h;
+        fr_store<F>(cG, k, fe_mul(fr_load<F>(cG, k), left ? ui : u));
+        fr_store<F>(cH, k, fe_mul(fr_load<F>(cH, k), left ? u : ui));
+    }
     if (k < h) {
         Fe<F> aL = fr_load<F>(a, k), aR = fr_load<F>(a, h + k), bL = fr_load<F>(b, k), bR = fr_load<F>(b, h + k);
         fr_store<F>(a, k, fe_add(fe_mul(aL, u), fe_mul(ui, aR)));

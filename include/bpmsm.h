@@ -87,7 +87,7 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_REDUCE_M 2    /* buckets per bucket-reduce thread: a power of two in [1, 16384] */
 #define BP_TUNE_TASK_TARGET 3 /* number of tasks the accumulate kernel aims at: [1024, 2^28] */
 #define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 512 terms */
-#define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 8 (0: 4 when a fold has >= 48 records, else 1) */
+#define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
 /* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
  * of a small proof; blocks are recycled in stream order).  bp_ctx_trim returns the cached blocks to the driver. */
@@ -311,6 +311,16 @@ int bp_ipp_state_free(bp_ipp_state* st);
 int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
                   const bp_g1vec* H, const bp_frvec* a, const bp_frvec* b, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out,
                   uint8_t* a_out_le32, uint8_t* b_out_le32);
+/* IPP::create_ipp with the generators SHARDED BY INDEX RANGE over several contexts / devices: shard i = (G[i], H[i],
+ * G_factors[i], H_factors[i]) is resident with ctxs[i] and covers the next G[i]->n indices; the sizes add up to n (a power of two).
+ * a, b arrive as host scalars (n x 32 bytes, canonical) and are replicated.  Every round each shard runs its slice of the L / R
+ * MSMs with one common window width; the record sets are gathered through pinned host memory and folded on the calling thread
+ * (as bp_msm_g1_multi).  Same proof bytes as bp_ipp_create.  Pays only for n >= 2^18 or with window tables on every shard's G, H
+ * (DESIGN.md section 6); exists so that a generator set too large for one device, or already distributed, needs no gathering. */
+int bp_ipp_create_multi(bp_ctx* const* ctxs, size_t n_shards, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* const* G_factors,
+                        const bp_frvec* const* H_factors, const bp_g1vec* const* G, const bp_g1vec* const* H, const uint8_t* a_le32,
+                        const uint8_t* b_le32, size_t n, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out_le32,
+                        uint8_t* b_out_le32);
 /* IPP::verify_ipp (src/ipp.rs:204-260): BP_OK, or BP_ERR_VERIFY (R1CSError::VerificationError) when the single
  * (1 + 2n + 2 lg n)-term MSM differs from P or when lg_n >= 32 / n != 2^lg_n (src/ipp.rs:269-276). */
 int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_factors, const bp_frvec* H_factors, const uint8_t* P_le,

@@ -12,7 +12,7 @@ ctxs = {0: bp.Context(0, 0), 1: bp.Context(1, 0)}
 t_end, cases, fails = time.time() + budget, 0, 0
 while time.time() < t_end:
     cid = rnd.randrange(2); ctx = ctxs[cid]; r = ctx.r
-    n = rnd.choice([1, 2, 4, 8, 16, 32, 64, 128])
+    n = rnd.choice([1, 2, 4, 8, 16, 32, 64, 128, 256, 512])         # >= 256: the rounds leave the single-launch path; tables can engage
     ctx.set_ipp_fold_generators(rnd.random() < 0.3)
     seed = rnd.randrange(1 << 30)
     Gv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, seed, n), n))
@@ -27,6 +27,9 @@ while time.time() < t_end:
     gfb, hfb = vec(rnd.choice(["ones", "rand"]), seed + 5), vec(rnd.choice(["ones", "rand"]), seed + 6)
     dev = lambda b: bp.FieldElementVector.from_bytes(ctx, b, n)
     a, b, Gf, Hf = dev(ab), dev(bb), dev(gfb), dev(hfb)
+    if n >= 256 and rnd.random() < 0.5:                              # round 3: precomputed generators (same or different widths)
+        cG = rnd.choice([0, 16, rnd.randrange(6, 17)])
+        Gv.precompute(cG); Hv.precompute(cG if rnd.random() < 0.8 else rnd.randrange(6, 17))
     proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"fuzz"), Q, Gf, Hf, Gv, Hv, a, b)
     rc, want = O.ipp_create(cid, O.Transcript(b"fuzz"), Q, gfb, hfb, Gv.to_bytes(), Hv.to_bytes(), ab, bb, n)
     ok = rc == 0 and (proof.L, proof.R, proof.a, proof.b) == want

@@ -45,6 +45,13 @@ while time.time() < t_end:
     ctx.set_window_bits(c)
     ctx.set_device_tail(rnd.random() < 0.05)
     pv = bp.G1Vector.from_bytes(ctx, pts, n); sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+    tabled = rnd.random() < 0.3                                   # round 3: window-multiples table (merged-window pipeline), any width
+    if tabled: pv.precompute(rnd.choice([0, 16, rnd.randrange(2, 17)]))
+    knobs = rnd.random() < 0.2                                    # round 3: validated tuning knobs must never change a result
+    if knobs:
+        ctx.set_tuning(bp.TUNE_TILE, rnd.choice([0, 256, 512, 4096, 16384])); ctx.set_tuning(bp.TUNE_REDUCE_M, rnd.choice([0, 1, 2, 4, 16, 64]))
+        ctx.set_tuning(bp.TUNE_TASK_TARGET, rnd.choice([0, 1024, 1 << 16, 1 << 22])); ctx.set_tuning(bp.TUNE_TAIL_CHAINS, rnd.choice([0, 1, 3, 8]))
+        ctx.set_tuning(bp.TUNE_SMALL_MSM, rnd.choice([0, 1]))
     want = O.msm(cid, pts, ss, n, algo=O.PIPPENGER, nthreads=8)
     mode = rnd.choice(["msm", "pair", "beginend"])
     if mode == "msm": got = pv.multi_scalar_mul_var_time(sv)
@@ -56,8 +63,11 @@ while time.time() < t_end:
             fails += 1; print("FAIL pair second", cid, n, kind, ptmode, c, flush=True)
     cases += 1
     if got != want:
-        fails += 1; print("FAIL", mode, cid, n, kind, ptmode, c, flush=True)
+        fails += 1; print("FAIL", mode, cid, n, kind, ptmode, c, "tabled" if tabled else "", "knobs" if knobs else "", flush=True)
     ctx.set_window_bits(0); ctx.set_device_tail(False)
+    if knobs:
+        for k in (bp.TUNE_TILE, bp.TUNE_REDUCE_M, bp.TUNE_TASK_TARGET, bp.TUNE_TAIL_CHAINS): ctx.set_tuning(k, 0)
+        ctx.set_tuning(bp.TUNE_SMALL_MSM, 1)
     if cases % 50 == 0: print("cases", cases, "fails", fails, flush=True)
 print("done: cases", cases, "fails", fails, flush=True)
 sys.exit(1 if fails else 0)

@@ -339,5 +339,22 @@ def test_two_gpus_rccl_and_multi_device_contexts(bp):
         pv.append(bp.G1Vector.fixed_base(c, bp.FieldElementVector.from_bytes(c, kb, half)))
         svs.append(bp.FieldElementVector.from_bytes(c, sb, half))
     assert bp.msm_multi(ctxs, pv, svs) == want
+    # the inner-product argument with its generators sharded over the two devices: the single-device proof, byte for byte
+    m = 1024
+    gk, hk = O.random_scalars(cid, 83, m), O.random_scalars(cid, 84, m)
+    ab, bb, gfb, hfb = (O.random_scalars(cid, 85 + i, m) for i in range(4))
+    Q = O.g1_mul(cid, O.random_scalars(cid, 89, 1), O.generator(cid))
+    fe = lambda c, b, k: bp.FieldElementVector.from_bytes(c, b, k)
+    Gv, Hv = bp.G1Vector.fixed_base(ctxs[0], fe(ctxs[0], gk, m)), bp.G1Vector.fixed_base(ctxs[0], fe(ctxs[0], hk, m))
+    single = bp.IPP.create_ipp(ctxs[0], bp.Transcript(b"2gpu"), Q, fe(ctxs[0], gfb, m), fe(ctxs[0], hfb, m), Gv, Hv, fe(ctxs[0], ab, m), fe(ctxs[0], bb, m))
+    gb, hb, pb = Gv.to_bytes(), Hv.to_bytes(), ctxs[0].point_bytes
+    cut = 400
+    spans = ((0, cut), (cut, m))
+    Gs = [bp.G1Vector.from_bytes(c, gb[lo * pb:hi * pb], hi - lo) for c, (lo, hi) in zip(ctxs, spans)]
+    Hs = [bp.G1Vector.from_bytes(c, hb[lo * pb:hi * pb], hi - lo) for c, (lo, hi) in zip(ctxs, spans)]
+    Gfs = [fe(c, gfb[lo * 32:hi * 32], hi - lo) for c, (lo, hi) in zip(ctxs, spans)]
+    Hfs = [fe(c, hfb[lo * 32:hi * 32], hi - lo) for c, (lo, hi) in zip(ctxs, spans)]
+    multi = bp.IPP.create_ipp_multi(ctxs, bp.Transcript(b"2gpu"), Q, Gfs, Hfs, Gs, Hs, ab, bb)
+    assert (multi.L, multi.R, multi.a, multi.b) == (single.L, single.R, single.a, single.b)
     for c in ctxs:
         c.close()

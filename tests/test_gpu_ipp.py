@@ -257,6 +257,50 @@ def test_ipp_with_precomputed_generators(bp, ctxs, name, n, c):
     bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, tabled.a, tabled.b, tabled.L, tabled.R)
 
 
+@pytest.mark.parametrize("name,n,cuts,tables", [("bls12_381", 256, (0, 100, 256), False), ("bls12_381", 1024, (0, 300, 301, 1024), True),
+                                                   ("bn254", 512, (0, 256, 512), True), ("bn254", 64, (0, 1, 33, 64), False), ("bls12_381", 2, (0, 1, 2), False)])
+def test_ipp_sharded_over_contexts(bp, ctxs, name, n, cuts, tables):
+    """SURVEY 8e, second sentence: the generators sharded by index range over several contexts (bp_ipp_create_multi; here the
+    contexts share one device, on a multi-GPU box they would not).  Ragged shards, with and without window tables: the proof must be
+    the single-context proof and the oracle's, byte for byte."""
+    main = ctxs[name]
+    cid = main.curve
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, main, n, 31000 + n, unit_gf=False)
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(),
+                            b.to_bytes(), n)
+    assert rc == 0
+    single = bp.IPP.create_ipp(main, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert (single.L, single.R, single.a, single.b) == want
+    shards = [bp.Context(cid, 0) for _ in range(len(cuts) - 1)]
+    pb = main.point_bytes
+    gb, hb, gfb, hfb = Gv.to_bytes(), Hv.to_bytes(), Gf.to_bytes(), Hf.to_bytes()
+    Gs, Hs, Gfs, Hfs = [], [], [], []
+    for c, lo, hi in zip(shards, cuts[:-1], cuts[1:]):
+        Gs.append(bp.G1Vector.from_bytes(c, gb[lo * pb:hi * pb], hi - lo))
+        Hs.append(bp.G1Vector.from_bytes(c, hb[lo * pb:hi * pb], hi - lo))
+        Gfs.append(bp.FieldElementVector.from_bytes(c, gfb[lo * 32:hi * 32], hi - lo))
+        Hfs.append(bp.FieldElementVector.from_bytes(c, hfb[lo * 32:hi * 32], hi - lo))
+        if tables:
+            Gs[-1].precompute(16)
+            Hs[-1].precompute(16)
+    proof = bp.IPP.create_ipp_multi(shards, bp.Transcript(b"innerproduct"), Q, Gfs, Hfs, Gs, Hs, a.to_bytes(), b.to_bytes())
+    assert (proof.L, proof.R, proof.a, proof.b) == want
+    P = commitment_P(bp, main, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(main, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+    # argument checks: sizes that do not add up to a power of two, a context used twice, a non-canonical scalar
+    rest = cuts[-2]
+    if rest & (rest - 1):
+        with pytest.raises(bp.ArgError):
+            bp.IPP.create_ipp_multi(shards[:-1], bp.Transcript(b"innerproduct"), Q, Gfs[:-1], Hfs[:-1], Gs[:-1], Hs[:-1], a.to_bytes(), b.to_bytes())
+    if len(shards) > 1:
+        with pytest.raises(bp.ArgError):
+            bp.IPP.create_ipp_multi([shards[0]] * len(shards), bp.Transcript(b"innerproduct"), Q, Gfs, Hfs, Gs, Hs, a.to_bytes(), b.to_bytes())
+    with pytest.raises(bp.ArgError):
+        bp.IPP.create_ipp_multi(shards, bp.Transcript(b"innerproduct"), Q, Gfs, Hfs, Gs, Hs, b"\xff" * 32 + a.to_bytes()[32:], b.to_bytes())
+    for c in shards:
+        c.close()
+
+
 @pytest.mark.parametrize("name", CURVES)
 def test_ipp_round_api_with_external_transcript(bp, ctxs, name, prover_mode):
     """The low-level state API driven by a transcript the caller owns (here: the oracle's), as a Rust host would."""

@@ -325,8 +325,8 @@ def test_begin_end_two_contexts_one_thread(bp):
 
 def test_short_differential_fuzz():
     """A few seconds of scripts/fuzz_msm.py and scripts/fuzz_ipp.py (random sizes, window widths, scalar structure,
-    identity / duplicate / negated points, both prover modes) against the oracle.  Longer runs of the same scripts during
-    development: 23 495 MSM cases and 3 326 IPP cases without a mismatch."""
+    identity / duplicate / negated points, window tables, tuning knobs, both prover modes) against the oracle.  Longer runs of the
+    same scripts after every kernel change: totals per round in DESIGN.md section 2."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for script, secs in (("fuzz_msm.py", "6"), ("fuzz_ipp.py", "6")):
