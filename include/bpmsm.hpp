@@ -147,6 +147,10 @@ public:
         check(bp_g1vec_compress(ctx_->handle(), h_, 0, len(), out.data()), "bp_g1vec_compress");
         return out;
     }
+    // window-multiples table for a fixed generator vector (bp_g1vec_precompute): every later MSM over the whole vector, and the
+    // IPP / R1CS provers that take it as G or H, run merged-window; same bytes with and without
+    void precompute(int window_bits = 0) { check(bp_g1vec_precompute(ctx_->handle(), h_, window_bits), "bp_g1vec_precompute"); }
+    void drop_table() { check(bp_g1vec_drop_table(h_), "bp_g1vec_drop_table"); }
     size_t len() const { return bp_g1vec_len(h_); }
     Bytes to_bytes() const {
         Bytes out(len() * ctx_->point_bytes());
@@ -228,6 +232,36 @@ struct IPP {
         (void)n;
         p.L.resize(lg * ctx.point_bytes());
         p.R.resize(lg * ctx.point_bytes());
+        return p;
+    }
+    // create_ipp with the generators sharded by index range over several contexts / devices (bp_ipp_create_multi); a, b as n x 32-byte
+    // host scalars.  Same proof bytes as create_ipp.
+    static InnerProductArgumentProof create_ipp_sharded(const std::vector<Context*>& ctxs, Transcript& transcript, const Bytes& Q,
+                                                        const std::vector<const FieldElementVector*>& G_factors,
+                                                        const std::vector<const FieldElementVector*>& H_factors, const std::vector<const G1Vector*>& G_vecs,
+                                                        const std::vector<const G1Vector*>& H_vecs, const Bytes& a_le32, const Bytes& b_le32) {
+        const size_t k = ctxs.size();
+        if (k == 0 || G_factors.size() != k || H_factors.size() != k || G_vecs.size() != k || H_vecs.size() != k) throw ValueError("create_ipp_sharded", BP_ERR_LENGTH);
+        std::vector<bp_ctx*> c;
+        std::vector<const bp_frvec*> gf, hf;
+        std::vector<const bp_g1vec*> g, h;
+        size_t n = 0, lg = 0;
+        for (size_t i = 0; i < k; i++) {
+            c.push_back(ctxs[i]->handle()); gf.push_back(G_factors[i]->handle()); hf.push_back(H_factors[i]->handle());
+            g.push_back(G_vecs[i]->handle()); h.push_back(H_vecs[i]->handle());
+            n += G_vecs[i]->len();
+        }
+        if (a_le32.size() != 32 * n || b_le32.size() != 32 * n) throw ValueError("create_ipp_sharded", BP_ERR_LENGTH);
+        InnerProductArgumentProof p;
+        p.L.resize(64 * ctxs[0]->point_bytes());
+        p.R.resize(64 * ctxs[0]->point_bytes());
+        p.a.resize(32);
+        p.b.resize(32);
+        check(bp_ipp_create_multi(c.data(), k, transcript.handle(), Q.data(), gf.data(), hf.data(), g.data(), h.data(), a_le32.data(), b_le32.data(), n,
+                                  p.L.data(), p.R.data(), &lg, p.a.data(), p.b.data()),
+              "bp_ipp_create_multi");
+        p.L.resize(lg * ctxs[0]->point_bytes());
+        p.R.resize(lg * ctxs[0]->point_bytes());
         return p;
     }
     // src/ipp.rs:204-260: returns on success, throws VerificationError otherwise (Result<(), R1CSError>)

@@ -131,6 +131,21 @@ static int gpu_mode(int curve) {
         bp::G1Vector p_lo(ctx, bp::Bytes(pb_all.begin(), pb_all.begin() + half * pb)), p_hi(ctx2, bp::Bytes(pb_all.begin() + half * pb, pb_all.end()));
         bp::FieldElementVector s_lo(ctx, bp::Bytes(sc_all.begin(), sc_all.begin() + half * 32)), s_hi(ctx2, bp::Bytes(sc_all.begin() + half * 32, sc_all.end()));
         if (bp::G1Vector::multi_scalar_mul_var_time_sharded({&ctx, &ctx2}, {&p_lo, &p_hi}, {&s_lo, &s_hi}) != P2) { printf("sharded MSM differs\n"); return 1; }
+        // round 3: a window-multiples table changes no byte of an MSM ...
+        pts2.precompute(7);
+        if (pts2.multi_scalar_mul_var_time(sc) != P2) { printf("MSM over a table differs\n"); return 1; }
+        pts2.drop_table();
+        // ... and create_ipp with the generators sharded over two contexts is create_ipp
+        const size_t ng = Gh.len(), cut = ng / 2 ? ng / 2 : 1;
+        if (ng >= 2) {
+            bp::Bytes gb = Gh.to_bytes(), hb = Hh.to_bytes(), gfb = G_factors.to_bytes(), hfb = H_factors.to_bytes();
+            auto pt = [&](const bp::Bytes& v, size_t lo, size_t hi, size_t w) { return bp::Bytes(v.begin() + lo * w, v.begin() + hi * w); };
+            bp::G1Vector g0(ctx, pt(gb, 0, cut, pb)), g1(ctx2, pt(gb, cut, ng, pb)), h0(ctx, pt(hb, 0, cut, pb)), h1(ctx2, pt(hb, cut, ng, pb));
+            bp::FieldElementVector gf0(ctx, pt(gfb, 0, cut, 32)), gf1(ctx2, pt(gfb, cut, ng, 32)), hf0(ctx, pt(hfb, 0, cut, 32)), hf1(ctx2, pt(hfb, cut, ng, 32));
+            bp::Transcript ts("innerproduct");
+            bp::InnerProductArgumentProof ps = bp::IPP::create_ipp_sharded({&ctx, &ctx2}, ts, Qh, {&gf0, &gf1}, {&hf0, &hf1}, {&g0, &g1}, {&h0, &h1}, a.to_bytes(), b.to_bytes());
+            if (ps.L != proof2.L || ps.R != proof2.R || ps.a != proof2.a || ps.b != proof2.b) { printf("sharded IPP differs\n"); return 1; }
+        }
     }
     printf("cpp gpu ok curve=%d a=%s\n", curve, hex(proof.a).c_str());
     return 0;
