@@ -454,8 +454,9 @@ def main():
     # ---- extras in the SAME line (never `value`): what the driver's one command would otherwise not measure -------
     #   N = 1: the n = 2^16 .. 2^22 sweep of north_star (best of 5 each, every size verified by linearity)
     #   N > 1: BASELINE config 4 -- a 2^22-point MSM split by index range over the N ranks (strong scaling)
-    extras = not args.no_extras and not args.strong and args.curve == "bls12_381" and (args.lg_n == 20 or args.extras) and not failed
-    if extras and world == 1:
+    # (the decision must be the same on every rank: it gates collectives.  `failed` is only known to rank 0, so it gates the N = 1 sweep alone.)
+    extras = not args.no_extras and not args.strong and args.curve == "bls12_381" and (args.lg_n == 20 or args.extras)
+    if extras and world == 1 and not failed:
         out["sweep"] = size_sweep(bp, ctx, curve, info, unit_bytes, lgs=tuple(range(min(16, args.sweep_max_lg), args.sweep_max_lg + 1)))
     if extras and world > 1:
         st = strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=args.strong_lg)
