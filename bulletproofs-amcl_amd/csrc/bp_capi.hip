@@ -254,9 +254,14 @@ struct Impl {
             return BP_OK;
         }
         const size_t nb = tab.nbuckets;
-        // task length (see bp_kernels.cuh): >= 2x the mean bucket size when buckets are plentiful, else small enough
-        // for ~task_target tasks (a few times the 131072 resident lanes of k_accumulate)
-        const uint64_t kTaskTarget = ctx->tuning.task_target ? ctx->tuning.task_target : 2 * 131072;
+        // Task length (task_len, bp_kernels.cuh): chosen on the device from the entries and non-empty buckets the sort finds.  The host
+        // computes the same rule for the worst case -- every digit non-zero, every bucket used -- to SIZE the task arrays: the device
+        // may go down to an eighth of it (structured scalars: few entries, few buckets), never below.
+        // (target: 1.5x the 131 072 resident lanes of k_accumulate.  It was 2x while the length came from the host's n W; with the true
+        // entry count an inner-product round -- half of each scalar set is zero -- fell to L = 8, four task sums per bucket for the
+        // reduce to add: accumulate -22 us, reduce +50 us per round on one box.  1.5x restores L = 16 there; uniform MSMs of 2^14 ..
+        // 2^20 measured the same at 1x, 1.5x and 2x.)
+        const uint64_t kTaskTarget = ctx->tuning.task_target ? ctx->tuning.task_target : 3 * 65536;
         const uint64_t entries = (uint64_t)W * (nnz ? nnz : n);
         uint32_t L = 8;
         // (Round 3 tried "plentiful" from a quarter of the target on, so that the 2^16 merged buckets of a table MSM stay one task each
@@ -264,8 +269,8 @@ struct Impl {
         // bucket -- one task per lane, nothing to balance -- 0.31 -> 0.51 ms.  Kept as it was.)
         if (nb >= kTaskTarget) { while ((uint64_t)L * nb < 2 * entries && L < (1u << 20)) L <<= 1; if (L < 128) L = 128; }
         else { while ((uint64_t)L * kTaskTarget < entries && L < (1u << 20)) L <<= 1; }
-        uint32_t lshift = 0;
-        while ((128u << lshift) < L) lshift++;
+        const uint32_t lmin = L / 8 > 8 ? L / 8 : 8;
+        L = lmin;                                                           // what the arrays are sized for
         const size_t slots = (size_t)W * n;
         size_t max_split = slots / L + 1;                                 // tasks beyond one per bucket
         if (max_split > slots) max_split = slots;
@@ -285,7 +290,7 @@ struct Impl {
         if ((rc = ctx->tsum.reserve(ctx, max_tasks * kXyzzBytes))) return rc;
         if ((rc = ctx->heavy.reserve(ctx, max_heavy * 4))) return rc;
         if ((rc = ctx->heavy_chunks.reserve(ctx, max_chunks * sizeof(uint2)))) return rc;
-        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16 + kMaxWindows;      // + one "blocks done" counter per window (k_bucket_reduce)
+        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16 + 2 * kMaxWindows;      // + per window: "blocks done" (k_bucket_reduce), non-empty buckets
         if ((rc = ctx->meta.reserve(ctx, kMetaWords * 4))) return rc;
         if ((rc = ctx->partial.reserve(ctx, (size_t)tabR.rboff[WR] * kPartPerBlock * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // bucket starts
@@ -320,6 +325,7 @@ struct Impl {
         uint32_t* nheavy = bins + kTaskBins + 1;
         uint32_t* nchunks = bins + kTaskBins + 2;
         uint32_t* win_done = bins + ((kTaskBins + 3 + 15) / 16) * 16;
+        uint32_t* nonempty = win_done + kMaxWindows;                    // per window: buckets that hold anything (k_fine_place -> task_len)
         uint32_t* order = (uint32_t*)ctx->order.p;
         uint32_t* t_start = (uint32_t*)ctx->t_start.p;
         uint32_t* t_len = (uint32_t*)ctx->t_len.p;
@@ -338,16 +344,16 @@ struct Impl {
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, W), dim3(kBlock), 0, st, code, n, tab, ntiles, tile_hist, tmp_rec, 0, tile);
         BP_TRACE_SYNC(ctx, "k_coarse_scatter");
-        hipLaunchKernelGGL(k_fine_place, dim3(128, WR), dim3(kBlock), 0, st, tmp_rec, tabR, ncols, tile_hist, hsum + hist_blocks, count, cursor, idx, 0);
+        hipLaunchKernelGGL(k_fine_place, dim3(128, WR), dim3(kBlock), 0, st, tmp_rec, tabR, ncols, tile_hist, hsum + hist_blocks, count, cursor, idx, 0, nonempty);
         BP_TRACE_SYNC(ctx, "k_fine_place");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[3], st));
         // count[] = bucket starts, cursor[] = bucket ends
         const unsigned bgrid = (unsigned)((nb + kBlock * kTaskPer - 1) / (kBlock * kTaskPer));   // kTaskPer buckets per lane
-        hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, ntasks, bins);
+        hipLaunchKernelGGL(k_task_count, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, hsum + hist_blocks, nonempty, (uint32_t)WR, (uint32_t)kTaskTarget, lmin, ntasks, bins);
         hipLaunchKernelGGL(k_task_bins_scan, dim3(1), dim3(kBlock), 0, st, bins, total_tasks);
         hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)scan_blocks), dim3(kBlock), 0, st, ntasks, nb, bsum, task_off, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, L, lshift, task_off, bins, order, t_start, t_len,
+        hipLaunchKernelGGL(k_task_emit, dim3(bgrid), dim3(kBlock), 0, st, count, cursor, (uint32_t)nb, hsum + hist_blocks, nonempty, (uint32_t)WR, (uint32_t)kTaskTarget, lmin, task_off, bins, order, t_start, t_len,
                            heavy, nheavy, chunks, nchunks);
         BP_TRACE_SYNC(ctx, "k_task_emit");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[4], st));

@@ -198,7 +198,8 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
 // coarse bin (row = hoff[w] + bin; `total` closes the last row).  Two streaming passes over them: fine histogram,
 // then placement.  Writes start[g] / end[g] for its 2^fbits buckets and idx[] (point index + sign bit).
 static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __restrict__ tmp_rec, WinTab tab, uint32_t ntiles, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ total,
-                                                             uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx, int w0) {
+                                                             uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx, int w0,
+                                                             uint32_t* __restrict__ nonempty) {
     __shared__ uint32_t lh[kBlock], lscan[kBlock / 64];
     const int w = w0 + (int)blockIdx.y;
     const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
@@ -229,6 +230,11 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
         uint32_t g = tab.boff[w] + (blockIdx.x << fb) + threadIdx.x;
         start[g] = ex;
         end[g] = ex + cnt;
+    }
+    {   // buckets that hold anything, for the task length (task_len below): one atomic per block, on its WINDOW's counter (one
+        // counter for all blocks -- 2 432 blocks x 4 waves at n = 2^16 -- serialised in L2: +26 us on a 25 us stage)
+        const int ne = __syncthreads_count(threadIdx.x <= fmask && cnt != 0);
+        if (threadIdx.x == 0 && ne) atomicAdd(&nonempty[w], (uint32_t)ne);
     }
     lh[threadIdx.x] = ex;
     __syncthreads();
@@ -312,10 +318,44 @@ static __global__ void __launch_bounds__(kBlock) k_scan_apply(const uint32_t* in
 // points into one bucket).  Tasks are then ordered by length, longest first (counting sort), so that the 64
 // lanes of a wave run the same number of additions: with Poisson(32) bucket sizes an unsorted wave waits for
 // its longest lane, ~1.45x the mean.
-// The task length L is a power of two chosen per call: when there are plenty of buckets (>> resident lanes) it is
+// The task length L is a power of two chosen per call (task_len): when there are plenty of buckets (>> resident lanes) it is
 // >= 2x the mean bucket size, so that with uniformly random scalars every bucket is one task; when buckets are few it
 // is smaller, so that there are several times more tasks than lanes (otherwise the last, partly filled round of
 // waves costs up to half of the kernel).  Lengths are binned into <= 129 classes, longest first.
+// Round 3: L is chosen ON THE DEVICE (task_len), from what the sort found -- E entries in NE non-empty buckets -- instead of on the
+// host from n W entries in all buckets: scalars with structure (bit vectors, small values, repeated values: the a_L / a_R and value
+// commitments of a range proof) fill a handful of buckets of a single window, the host's "every bucket is one task of <= 128" then
+// meant 128 dependent additions on a few thousand lanes (accumulate 1.05 ms for 2^17 useful additions at n = 2^18, bits).  The
+// host still sizes the task arrays: lmin (its own estimate / 8) bounds L from below.
+struct TaskLen { uint32_t L, lshift; };
+__device__ __forceinline__ TaskLen task_len(uint32_t entries, const uint32_t* __restrict__ nonempty_w, uint32_t nwin, uint32_t target, uint32_t lmin) {
+    __shared__ uint32_t s_ne;                 // non-empty buckets: the sum of the per-window counters of k_fine_place (nwin <= kBlock)
+    if (threadIdx.x == 0) s_ne = 0;
+    __syncthreads();
+    if (threadIdx.x < nwin) { const uint32_t v = nonempty_w[threadIdx.x]; if (v) atomicAdd(&s_ne, v); }
+    __syncthreads();
+    const uint64_t E = entries, NE = s_ne ? s_ne : 1;
+    uint64_t L = 8;
+    if (NE >= target) {                       // plenty of buckets: every one of them a single task (twice the mean, at least 128)
+        while (L * NE < 2 * E && L < (1u << 20)) L <<= 1;
+        if (L < 128) L = 128;
+    } else {                                  // few buckets: ~target tasks ...
+        while (L * target < E && L < (1u << 20)) L <<= 1;
+        // ... unless that cuts EVERY bucket into more than kLightMax tasks (few, fat buckets: a narrow window-multiples table has 2^13
+        // buckets of ~300 points at c = 14, n = 2^17) and sends them all through k_combine_chunks, a block per bucket (measured: 5.2 ms
+        // per paired MSM against 0.9 ms at c = 16): then the length that leaves a typical bucket <= 6 tasks -- summed by the reduce's
+        // own lanes -- as long as a quarter of the resident lanes still get a task.
+        uint64_t L2 = L;
+        while (L2 * NE * 6 < E && L2 < (1u << 20)) L2 <<= 1;
+        if (L2 > L && E / L2 >= 32768) L = L2;
+    }
+    if (L < lmin) L = lmin;
+    TaskLen t;
+    t.L = (uint32_t)L;
+    t.lshift = 0;
+    while ((128u << t.lshift) < t.L) t.lshift++;
+    return t;
+}
 constexpr uint32_t kTaskBins = 129;
 constexpr uint32_t kLightMax = 8;   // buckets of 2..kLightMax tasks are summed inside k_bucket_reduce, heavier ones by k_combine_chunks / _heavy
 __device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t lshift) { return (L - len) >> lshift; }   // lshift = max(0, log2(L) - 7)
@@ -325,8 +365,11 @@ __device__ __forceinline__ uint32_t task_bin(uint32_t len, uint32_t L, uint32_t 
 // one bucket per lane (2048 blocks at 2^19 buckets) that serialised traffic was most of the kernel's 30 us.
 constexpr int kTaskPer = 4;
 static __global__ void __launch_bounds__(kBlock) k_task_count(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
-                                                        uint32_t L, uint32_t lshift, uint32_t* __restrict__ ntasks, uint32_t* __restrict__ bin_count) {
+                                                        const uint32_t* __restrict__ entries, const uint32_t* __restrict__ nonempty, uint32_t nwin, uint32_t target, uint32_t lmin,
+                                                        uint32_t* __restrict__ ntasks, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t lh[kTaskBins];
+    const TaskLen tl = task_len(*entries, nonempty, nwin, target, lmin);
+    const uint32_t L = tl.L, lshift = tl.lshift;
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
     __syncthreads();
     uint32_t sz[kTaskPer];
@@ -359,14 +402,20 @@ static __global__ void __launch_bounds__(kBlock) k_task_bins_scan(uint32_t* __re
 
 // thread per bucket: emit its tasks.  task id = task_off[g] + k; order[] lists task ids longest first (positions are
 // reserved per block through LDS histograms: one global atomic per (block, length class)).  t_start/t_len describe the
-// slot range of a task.  Buckets with more than kLightMax tasks are appended to heavy[], their kBlock-task chunks to chunks[].
+// slot range of a task.  Buckets with more than kLightMax tasks have their kBlock-task chunks appended to chunks[] (and the bucket
+// itself to heavy[] when it has more than one chunk).
 static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t nbuckets,
-                                                       uint32_t L, uint32_t lshift, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ bin_cursor,
+                                                       const uint32_t* __restrict__ entries, const uint32_t* __restrict__ nonempty, uint32_t nwin, uint32_t target, uint32_t lmin,
+                                                       const uint32_t* __restrict__ task_off, uint32_t* __restrict__ bin_cursor,
                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ t_start, uint32_t* __restrict__ t_len,
                                                        uint32_t* __restrict__ heavy, uint32_t* __restrict__ nheavy, uint2* __restrict__ chunks,
                                                        uint32_t* __restrict__ nchunks) {
     __shared__ uint32_t lh[kTaskBins], lbase[kTaskBins];
+    __shared__ uint32_t big_n, big[kBlock * kTaskPer][4];        // buckets of more than kSerialEmit full tasks: (first task id, first slot, full tasks, first position in order[])
+    const TaskLen tl = task_len(*entries, nonempty, nwin, target, lmin);      // the same inputs as k_task_count: the same length
+    const uint32_t L = tl.L, lshift = tl.lshift;
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lh[b] = 0;
+    if (threadIdx.x == 0) big_n = 0;
     __syncthreads();
     uint32_t size[kTaskPer], s0[kTaskPer], toff[kTaskPer], rank_full[kTaskPer], rank_rem[kTaskPer];
 #pragma unroll
@@ -384,15 +433,23 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kTaskBins; b += kBlock) lbase[b] = lh[b] ? atomicAdd(&bin_cursor[b], lh[b]) : 0;
     __syncthreads();
+    // A lane writes the tasks of its own bucket while they are few; a bucket of many tasks (one bucket holds HALF of all points when
+    // the scalars are bits: 32 768 tasks at n = 2^20, 1.1 ms for the one lane that owned it) is handed to the whole block.
+    constexpr uint32_t kSerialEmit = 16;
 #pragma unroll
     for (int u = 0; u < kTaskPer; u++) {
         if (size[u] == 0) continue;
         const uint32_t g = (blockIdx.x * kTaskPer + u) * kBlock + threadIdx.x;
         const uint32_t nfull = size[u] / L, rem = size[u] % L;
-        for (uint32_t k = 0; k < nfull; k++) {
-            order[lbase[0] + rank_full[u] + k] = toff[u] + k;
-            t_start[toff[u] + k] = s0[u] + k * L;
-            t_len[toff[u] + k] = L;
+        if (nfull <= kSerialEmit) {
+            for (uint32_t k = 0; k < nfull; k++) {
+                order[lbase[0] + rank_full[u] + k] = toff[u] + k;
+                t_start[toff[u] + k] = s0[u] + k * L;
+                t_len[toff[u] + k] = L;
+            }
+        } else {
+            const uint32_t slot = atomicAdd(&big_n, 1u);
+            big[slot][0] = toff[u]; big[slot][1] = s0[u]; big[slot][2] = nfull; big[slot][3] = lbase[0] + rank_full[u];
         }
         if (rem) {
             order[lbase[task_bin(rem, L, lshift)] + rank_rem[u]] = toff[u] + nfull;
@@ -401,10 +458,20 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
         }
         const uint32_t nt = nfull + (rem ? 1u : 0u);
         if (nt > kLightMax) {
-            heavy[atomicAdd(nheavy, 1u)] = g;
             const uint32_t nch = (nt + kBlock - 1) / kBlock;          // chunks of kBlock task sums for k_combine_chunks
+            if (nch > 1) heavy[atomicAdd(nheavy, 1u)] = g;            // k_combine_heavy: only buckets of several chunks
             const uint32_t base = atomicAdd(nchunks, nch);
             for (uint32_t j = 0; j < nch; j++) chunks[base + j] = make_uint2(g, j);
+        }
+    }
+    __syncthreads();
+    const uint32_t nbig = big_n;
+    for (uint32_t b = 0; b < nbig; b++) {
+        const uint32_t t0 = big[b][0], p0 = big[b][1], nfull = big[b][2], o0 = big[b][3];
+        for (uint32_t k = threadIdx.x; k < nfull; k += kBlock) {
+            order[o0 + k] = t0 + k;
+            t_start[t0 + k] = p0 + k * L;
+            t_len[t0 + k] = L;
         }
     }
 }
@@ -480,23 +547,61 @@ __device__ __forceinline__ XyzzLazy<C> block_tree_sum(XyzzLazy<C> mine, XyzzPack
 // Heavy buckets (more than kLightMax tasks) are folded in two stages so that one bucket holding most of the points -- 0/1
 // scalars, the a_L / a_R commitments of a range proof, put half of all points into ONE bucket: 4096 task sums at n = 2^16 --
 // is a tree over many blocks instead of one long chain (one wave: 64 + 6 dependent additions, 1.23 ms; chunked: 8 + 1 + 4):
-//   k_combine_chunks  block per (bucket, chunk of kBlock task sums), grid-stride over chunks[]: tree -> first record of the chunk
-//   k_combine_heavy   block per heavy bucket, grid-stride over heavy[]: sum of its chunk sums -> tsum[task_off[g]]
+//   k_combine_chunks  group of lanes per (bucket, chunk of kBlock task sums), grid-stride over chunks[]: -> first record of the chunk
+//   k_combine_heavy   block per bucket of SEVERAL chunks, grid-stride over heavy[]: sum of its chunk sums -> tsum[task_off[g]]
 // List lengths are only known on the device, so both grids are fixed-size and stride.
+// k_combine_chunks gives a chunk to a GROUP of G lanes, G chosen per launch so that the chunks fit one round of the grid where they
+// can: a block (G = 256, one task sum per lane, 8 tree levels) while there are at most as many chunks as blocks -- the one giant
+// bucket of bit scalars -- down to 4 lanes when there are thousands of them (256 distinct scalar values: 4096 buckets of 64 task sums,
+// 1.9 ms block-per-chunk, 16 rounds of a 6-level tree on 64 of 256 lanes; a window-multiples table at c = 14: 16 384 buckets of
+// 10).  Lane l of the group first adds the task sums l, l + G, ... of its chunk (a serial chain), then the group's tree runs over
+// the G partial sums.  ONE addition site serves both phases (code size: see plane_tree).
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_combine_chunks(const uint2* __restrict__ chunks, const uint32_t* __restrict__ nchunks,
                                                            const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks,
                                                            XyzzPacked<C>* __restrict__ tsum) {
     __shared__ XyzzPacked<C> lds[kBlock];
+    __shared__ uint32_t s_most;
     const uint32_t count = *nchunks;
-    for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
-        const uint2 gc = chunks[c];
-        const uint32_t first = task_off[gc.x] + gc.y * kBlock, left = ntasks[gc.x] - gc.y * kBlock;
-        const uint32_t cnt = left < (uint32_t)kBlock ? left : (uint32_t)kBlock;
-        XyzzLazy<C> mine = threadIdx.x < cnt ? xyzz_lazy_unpack(tsum[first + threadIdx.x]) : xyzz_lazy_inf<C>();
-        mine = block_tree_sum<C>(mine, lds, (int)cnt);
-        if (threadIdx.x == 0) tsum[first] = xyzz_lazy_pack(mine);
-        __syncthreads();   // lds is reused by the next chunk
+    uint32_t G = kBlock, lgG = 8;
+    while (G > 4 && (uint64_t)count > (uint64_t)gridDim.x * (kBlock / G)) { G >>= 1; lgG--; }
+    const uint32_t gpb = kBlock / G, lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    for (uint32_t c0 = blockIdx.x * gpb; c0 < count; c0 += gridDim.x * gpb) {         // block-uniform bounds
+        const uint32_t c = c0 + grp;
+        uint32_t first = 0, cnt = 0;
+        if (c < count) {
+            const uint2 gc = chunks[c];
+            const uint32_t left = ntasks[gc.x] - gc.y * kBlock;
+            first = task_off[gc.x] + gc.y * kBlock;
+            cnt = left < (uint32_t)kBlock ? left : (uint32_t)kBlock;
+        }
+        if (threadIdx.x == 0) s_most = 0;
+        __syncthreads();
+        if (lane == 0 && cnt) atomicMax(&s_most, cnt);
+        __syncthreads();
+        const uint32_t nser = (s_most + G - 1) / G;                 // serial steps of the longest chunk of this round (>= 1)
+        const uint32_t live = cnt < G ? cnt : G;                    // lanes of the group that hold a partial sum
+        XyzzLazy<C> mine = lane < cnt ? xyzz_lazy_unpack(tsum[first + lane]) : xyzz_lazy_inf<C>();
+#pragma unroll 1
+        for (uint32_t t = 1; t < nser + lgG; t++) {
+            XyzzLazy<C> b = xyzz_lazy_inf<C>();
+            bool have;
+            if (t < nser) {                                         // serial phase: my next task sum
+                const uint32_t k = lane + t * G;
+                have = k < cnt;
+                if (have) b = xyzz_lazy_unpack(tsum[first + k]);
+            } else {                                                // tree phase, stride G / 2, G / 4, ..., 1
+                const uint32_t st = G >> (t - nser + 1);
+                lds[threadIdx.x] = xyzz_lazy_pack(mine);
+                __syncthreads();
+                have = lane < st && lane + st < live;
+                if (have) b = xyzz_lazy_unpack(lds[threadIdx.x + st]);
+                __syncthreads();                                    // read before the next level overwrites
+            }
+            if (have) mine = xyzz_lazy_add(mine, b);
+        }
+        if (lane == 0 && cnt) tsum[first] = xyzz_lazy_pack(mine);
+        __syncthreads();                                            // s_most and lds are reused by the next round
     }
 }
 

@@ -27,6 +27,8 @@ def main():
         ctx.set_window_bits(int(os.environ["TIME_IPP_C"]))       # window width for every MSM of the run (0 = the library's rule)
     if os.environ.get("TIME_IPP_CHAINS"):
         ctx.set_tuning(bp.TUNE_TAIL_CHAINS, int(os.environ["TIME_IPP_CHAINS"]))
+    if os.environ.get("TIME_IPP_TASK_TARGET"):
+        ctx.set_tuning(bp.TUNE_TASK_TARGET, int(os.environ["TIME_IPP_TASK_TARGET"]))
     for lg in lgs:
         n = 1 << lg
         Gv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, rs(n, 1), n))

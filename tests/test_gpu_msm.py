@@ -299,6 +299,43 @@ def test_msm_heavy_skew_2e18(bp, ctxs, name):
     pts.free()
 
 
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_many_medium_buckets(bp, ctxs, name):
+    """Thousands of buckets of tens of task sums each -- the grouped k_combine_chunks (4 .. 256 lanes per chunk, chosen on the device)
+    and the task length the device derives from the sort's own counts: scalars with 256 / 4096 distinct values, 8-bit values, and
+    uniform scalars over narrow window-multiples tables (c = 12, 14: every bucket fat); also with the task target raised so that
+    every bucket is cut into many more tasks.  Checked by linearity."""
+    import random
+    ctx = bp.Context(bp.CURVE_IDS[name], 0)
+    try:
+        n = 1 << 17
+        ks = O.random_scalars(ctx.curve, 777, n)
+        pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+        gen = O.generator(ctx.curve)
+        rnd = random.Random(11)
+        pool = [rnd.getrandbits(250) for _ in range(4096)]
+        kinds = {
+            "256_values": [pool[rnd.randrange(256)] for _ in range(n)],
+            "4096_values": [pool[rnd.randrange(4096)] for _ in range(n)],
+            "8_bit": [rnd.getrandbits(8) for _ in range(n)],
+            "uniform": None,
+        }
+        for target in (0, 1 << 22):
+            ctx.set_tuning(bp.TUNE_TASK_TARGET, target)
+            for label, vals in kinds.items():
+                ss = O.random_scalars(ctx.curve, 778, n) if vals is None else b"".join(v.to_bytes(32, "little") for v in vals)
+                sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+                want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen)
+                assert pts.multi_scalar_mul_var_time(sv) == want, (label, target)
+                if vals is None:
+                    for c in (14, 12):
+                        pts.precompute(c)
+                        assert pts.multi_scalar_mul_var_time(sv) == want, (label, target, c)
+                    pts.drop_table()
+    finally:
+        ctx.close()
+
+
 def test_begin_end_two_contexts_one_thread(bp):
     """bp_msm_g1_begin / _end: two MSMs in flight from one host thread (two contexts, two streams)."""
     ca, cb = bp.Context(bp.BLS12_381, 0), bp.Context(bp.BLS12_381, 0)
