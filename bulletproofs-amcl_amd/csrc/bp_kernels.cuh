@@ -194,6 +194,10 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
     }
 }
 
+// (Structured scalars make ONE coarse bin huge -- bit vectors put half of all records into one bucket -- and its block then streams
+// 2^19 records alone: 0.89 ms at n = 2^20.  Peeling the wave's most common key off the LDS counters (one atomic per wave for it) was
+// measured in round 3: no gain for bits (the block is bound by its own load / store stream, not by the counter), 2x slower for a
+// huge bin with 255 live buckets (8-bit scalars).  The fix is several blocks per huge bin, i.e. a count / place pair of kernels.)
 // grid = (128, W); block (bin, w) owns the elements [tile_off[row * ntiles], tile_off[(row + 1) * ntiles]) of its
 // coarse bin (row = hoff[w] + bin; `total` closes the last row).  Two streaming passes over them: fine histogram,
 // then placement.  Writes start[g] / end[g] for its 2^fbits buckets and idx[] (point index + sign bit).
