@@ -111,7 +111,7 @@ static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets
     g.small = n <= kSmallMsmMax && small_ok && c_override <= 0;
     // k_small_msm (n <= kSmallMsmMax): each lane multiplies by its digit, so narrow windows shorten the chain; below c = 4 the
     // extra windows cost more on the host (one addition per window in the tail) than they save on the device
-    if (c_override <= 0 && g.small && c > 4) c = 4;
+    if (c_override <= 0 && g.small && c > kSmallDigitBits) c = kSmallDigitBits;
     if (c < 2) c = 2;
     if (c > 16) c = 16;
     g.c = c;
@@ -231,6 +231,8 @@ struct Impl {
     static int msm_windows(bp_ctx* ctx, const AffPacked<C>* pts, const ScalarWords* sc, size_t n, MsmGeom& g, const ScalarWords* sc2 = nullptr,
                            size_t nnz = 0, const bp_g1table* tb = nullptr) {
         // tb: window-multiples table of `pts` (same n): the merged-window pipeline over its rows
+        const bp_g1table* dm = nullptr;                     // digit multiples for the single-launch small MSM (bp_g1table::digits)
+        if (tb && tb->digits) { dm = tb; tb = nullptr; }
         int rc = tb ? msm_geom_table(g, C::Fr::BITS, tb->c, tb->W, sc2 ? 2 : 1, &ctx->tuning)
                     : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning);
         if (rc) return rc;
@@ -247,7 +249,9 @@ struct Impl {
         if ((rc = ctx->window_sum.reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         if (g.small) {   // one launch: block per window, lane per term (k_small_msm)
             if (tm) for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st));
-            hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p);
+            // the multiples only when they are this vector's and cover the digits of this geometry
+            const XyzzPacked<C>* mult = dm && dm->n == n && g.c <= dm->c ? (const XyzzPacked<C>*)dm->d : nullptr;
+            hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p, mult);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
             if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
             HIPCHK(hipGetLastError());
@@ -742,6 +746,27 @@ int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp
     else
         hipLaunchKernelGGL(k_table_build<Bn254>, grid, dim3(kBlock), 0, ctx->stream, (const AffPacked<Bn254>*)points, n, c, W1, (XyzzPacked<Bn254>*)tmp.p,
                            (FePacked<Bn254Fp>*)pre.p, (AffPacked<Bn254>*)t->d);
+    if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    *out = t;
+    return BP_OK;
+}
+
+// Digit multiples m P_i (m = 1 .. 8) of n <= kSmallMsmMax resident points for k_small_msm: one launch, ~100 us, n x 8 x 192 B.
+int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out) {
+    *out = nullptr;
+    if (n == 0 || n > kSmallMsmMax) return BP_ERR_ARG;
+    const size_t xz = bp_msm_record_bytes(ctx->curve);
+    const int rows = 1 << (kSmallDigitBits - 1);
+    bp_g1table* t = new (std::nothrow) bp_g1table();
+    if (!t) return BP_ERR_DEVICE;
+    t->pool = ctx->pool; t->device = ctx->device; t->n = n; t->c = kSmallDigitBits; t->W = rows; t->digits = true;
+    t->d = ctx->pool->get((size_t)rows * n * xz, &t->cap);
+    if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    const dim3 grid((unsigned)((n + 63) / 64));
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_digit_table_build<Bls381>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bls381>*)points, (uint32_t)n, (XyzzPacked<Bls381>*)t->d);
+    else
+        hipLaunchKernelGGL(k_digit_table_build<Bn254>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bn254>*)points, (uint32_t)n, (XyzzPacked<Bn254>*)t->d);
     if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     *out = t;
     return BP_OK;

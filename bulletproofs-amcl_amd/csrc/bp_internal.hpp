@@ -311,8 +311,13 @@ struct bp_g1table {
     size_t cap = 0;
     size_t n = 0;
     int c = 0, W = 0;
+    // digits == true: NOT window multiples but the digit multiples of the single-launch small MSM (k_small_msm): rows[(m - 1) * n + i]
+    // = m P_i for m = 1 .. 2^(c-1), packed lazy XYZZ (W = 2^(c-1) rows).  Built by the inner-product state for its [G | H | Q] when a
+    // round is <= kSmallMsmMax terms: the lanes then load their digit's multiple instead of computing it (library-internal).
+    bool digits = false;
 };
 extern "C" void bp_internal_table_free(bp_g1table* t);
+int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out);
 
 static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
 static inline bool curve_ok(int curve) { return curve == BP_CURVE_BLS12_381 || curve == BP_CURVE_BN254; }

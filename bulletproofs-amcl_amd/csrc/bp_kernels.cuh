@@ -798,10 +798,27 @@ __device__ __forceinline__ uint32_t window_bits(const uint64_t (&q)[4], int off,
     return (uint32_t)v & ((1u << cw) - 1);
 }
 
+// mult != nullptr (round 3): the digit multiples m P_t, m = 1 .. 2^(cmax-1), precomputed once for a vector that many small MSMs run
+// over (the [G | H | Q] of an inner-product argument of <= 255 generators: every round is an MSM over the same points).  The lane
+// then LOADS its term -- no doubling / mixed-addition bodies are executed (or fetched) at all, the kernel is its tree.
+constexpr int kSmallDigitBits = 4;     // the window width of the small path (msm_geom): |digit| <= 8
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>* __restrict__ pts, uint32_t n, XyzzPacked<C>* __restrict__ mult) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const Aff<C> p = aff_unpack(pts[t]);
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+#pragma unroll 1
+    for (uint32_t m = 1; m <= (1u << (kSmallDigitBits - 1)); m++) {       // one addition body: it handles the empty accumulator and P + P
+        xyzz_lazy_add_aff(acc, p);
+        mult[(size_t)(m - 1) * n + t] = xyzz_lazy_pack(acc);
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __restrict__ pts, const ScalarWords* __restrict__ sc1,
                                                       const ScalarWords* __restrict__ sc2, uint32_t n, WinTab tab,
-                                                      XyzzPacked<C>* __restrict__ window_sum) {
+                                                      XyzzPacked<C>* __restrict__ window_sum, const XyzzPacked<C>* __restrict__ mult) {
     __shared__ XyzzPacked<C> lds[kBlock];
     const int w = blockIdx.x, wps = tab.W / tab.nsets, set = w / wps;
     const int cw = tab.cw[w], off = tab.off[w];
@@ -811,13 +828,19 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
         int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
         if (d == 0) continue;
-        Aff<C> p = aff_unpack(pts[t]);
-        if (d < 0) { p.y = fe_neg(p.y); d = -d; }
-        XyzzLazy<C> acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
+        XyzzLazy<C> acc;
+        if (mult) {
+            acc = xyzz_lazy_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n + t]);
+            if (d < 0 && !acc.inf) acc.y = feb_neg<4>(acc.y);
+        } else {
+            Aff<C> p = aff_unpack(pts[t]);
+            if (d < 0) { p.y = fe_neg(p.y); d = -d; }
+            acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
 #pragma unroll 1
-        for (int i = 30 - __clz(d); i >= 0; i--) {            // bits below the leading one
-            acc = xyzz_lazy_dbl(acc);
-            if ((d >> i) & 1) xyzz_lazy_add_aff(acc, p);
+            for (int i = 30 - __clz(d); i >= 0; i--) {            // bits below the leading one
+                acc = xyzz_lazy_dbl(acc);
+                if ((d >> i) & 1) xyzz_lazy_add_aff(acc, p);
+            }
         }
         mine = xyzz_lazy_add(mine, acc);
     }
