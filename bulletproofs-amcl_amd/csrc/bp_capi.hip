@@ -14,6 +14,7 @@ struct MsmGeom {
     WinTab tab;      // W windows of nearly equal width covering fr_bits + 1 bits
     uint32_t m;      // buckets per reduce thread (a power of two; windows with fewer buckets use their bucket count)
     bool small;      // n <= kSmallMsmMax: the single-launch path, one record per window
+    int small_blocks; // ... per block of the window: 2 above kSmallMsmMax terms (only with the points' digit multiples), else 1
     bool merged;     // MSM over a window-multiples table: tab describes the digit windows, tabv the merged buckets (one "window" per scalar set)
     WinTab tabv;     // merged only: the view the kernels after the coarse scatter run with (k_fine_place .. k_window_sums)
     // tail records handed to the host: record r carries weight 2^rpos[r] (bp_host_tail.hpp folds any such list)
@@ -68,9 +69,9 @@ static int geom_reduce(MsmGeom& g, WinTab& t, const bp_tuning* tn) {
         t.rboff[w] = (uint16_t)rb;
         rb += nblk;
         t.roff[w] = (uint16_t)nrec;
-        if (g.small) {                                         // one record per window: the window sum itself
-            if (nrec < (uint32_t)kMaxRecords) g.rpos[nrec] = t.off[w];
-            nrec += 1;
+        if (g.small) {                                         // one record per window and block: the sum of the block's terms
+            for (int b = 0; b < g.small_blocks; b++) if (nrec + b < (uint32_t)kMaxRecords) g.rpos[nrec + b] = t.off[w];
+            nrec += (uint32_t)g.small_blocks;
         } else {                                               // tri, then one plane per bit of the reduce-thread index
             const int planes = ilog2(T);
             for (int k = 0; k <= planes; k++)
@@ -86,7 +87,7 @@ static int geom_reduce(MsmGeom& g, WinTab& t, const bp_tuning* tn) {
 }
 
 // tn: the context's validated tuning knobs (nullptr: defaults)
-static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0, const bp_tuning* tn = nullptr) {
+static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets = 1, size_t nnz = 0, const bp_tuning* tn = nullptr, size_t small_max = kSmallMsmMax) {
     int c = c_override;
     if (c <= 0) {
         int lg = 0;
@@ -108,7 +109,8 @@ static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets
     // The single-launch path emits one record per window, the bucket pipeline 1 + log2(reduce threads): callers that must agree on
     // a record layout across shards fix the window width (bp_ctx_set_window_bits / bp_msm_g1_multi), and a fixed width always means
     // the pipeline's layout -- a 5-point shard beside a 2^20-point one then folds with it.
-    g.small = n <= kSmallMsmMax && small_ok && c_override <= 0;
+    g.small = n <= small_max && small_ok && c_override <= 0;       // small_max: kSmallDigitMax when the caller holds the points' digit multiples
+    g.small_blocks = g.small && n > kSmallMsmMax ? 2 : 1;
     // k_small_msm (n <= kSmallMsmMax): each lane multiplies by its digit, so narrow windows shorten the chain; below c = 4 the
     // extra windows cost more on the host (one addition per window in the tail) than they save on the device
     if (c_override <= 0 && g.small && c > kSmallDigitBits) c = kSmallDigitBits;
@@ -172,6 +174,7 @@ static int msm_geom_table(MsmGeom& g, int fr_bits, int c, int W1, int nsets, con
     if (c < 2 || c > 16 || W1 != (cover + c - 1) / c || W1 * nsets > kMaxWindows) return BP_ERR_ARG;
     g.c = c;
     g.small = false;
+    g.small_blocks = 1;
     g.merged = true;
     WinTab& t = g.tab;
     memset(&t, 0, sizeof t);
@@ -234,7 +237,7 @@ struct Impl {
         const bp_g1table* dm = nullptr;                     // digit multiples for the single-launch small MSM (bp_g1table::digits)
         if (tb && tb->digits) { dm = tb; tb = nullptr; }
         int rc = tb ? msm_geom_table(g, C::Fr::BITS, tb->c, tb->W, sc2 ? 2 : 1, &ctx->tuning)
-                    : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning);
+                    : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning, dm && dm->n == n ? kSmallDigitMax : kSmallMsmMax);
         if (rc) return rc;
         if (tb) { if (tb->n != n || (uint64_t)tb->W * n >= ((uint64_t)1 << 31)) return BP_ERR_ARG; pts = (const AffPacked<C>*)tb->d; }
         const WinTab& tab = g.tab;                          // digit windows: k_digits_bin, k_coarse_scatter
@@ -251,7 +254,8 @@ struct Impl {
             if (tm) for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st));
             // the multiples only when they are this vector's and cover the digits of this geometry
             const XyzzPacked<C>* mult = dm && dm->n == n && g.c <= dm->c ? (const XyzzPacked<C>*)dm->d : nullptr;
-            hipLaunchKernelGGL(k_small_msm<C>, dim3(W), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p, mult);
+            if (g.small_blocks > 1 && !mult) return BP_ERR_ARG;    // (msm_geom only goes above kSmallMsmMax for a vector whose multiples it was shown)
+            hipLaunchKernelGGL(k_small_msm<C>, dim3(W, g.small_blocks), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p, mult);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
             if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
             HIPCHK(hipGetLastError());
@@ -507,7 +511,7 @@ struct Impl {
         h.magic = kRecMagic; h.c = (uint32_t)g.c; h.W = (uint32_t)g.tab.W; h.fr_bits = (uint32_t)C::Fr::BITS;
         h.cw_first = g.tab.cw[0]; h.cw_last = g.tab.cw[g.tab.W - 1];
         for (int w = 0; w < g.tab.W; w++) if (g.tab.cw[w] == g.tab.cw[0]) h.n_wide++;
-        h.nrec = (uint32_t)g.nrec; h.m = g.m; h.small = g.small ? 1u : 0u;
+        h.nrec = (uint32_t)g.nrec; h.m = g.m; h.small = g.small ? (uint32_t)g.small_blocks : 0u;
     }
 
     static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
@@ -751,10 +755,10 @@ int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp
     return BP_OK;
 }
 
-// Digit multiples m P_i (m = 1 .. 8) of n <= kSmallMsmMax resident points for k_small_msm: one launch, ~100 us, n x 8 x 192 B.
+// Digit multiples m P_i (m = 1 .. 8) of n <= kSmallDigitMax resident points for k_small_msm: one launch, ~100 us, n x 8 x 192 B.
 int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out) {
     *out = nullptr;
-    if (n == 0 || n > kSmallMsmMax) return BP_ERR_ARG;
+    if (n == 0 || n > kSmallDigitMax) return BP_ERR_ARG;
     const size_t xz = bp_msm_record_bytes(ctx->curve);
     const int rows = 1 << (kSmallDigitBits - 1);
     bp_g1table* t = new (std::nothrow) bp_g1table();

@@ -1018,10 +1018,11 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { bp_ipp_state_free(st); return BP_ERR_DEVICE; }
-    if (!st->fold_generators && 2 * n + 1 > kSmallMsmMax) {     // smaller rounds run as ONE launch (k_small_msm): nothing for a table to merge
+    const bool digits = !st->fold_generators && n >= 16 && 2 * n + 1 <= kSmallDigitMax && st->ctx->tuning.small_msm && st->ctx->c_override <= 0;
+    if (!st->fold_generators && !digits && 2 * n + 1 > kSmallMsmMax) {     // smaller rounds run as ONE launch (k_small_msm): nothing for a table to merge
         rc = bp_internal_table_concat(ctx, G, 0, H, 0, n, Q_le, &st->table);
         if (rc) { bp_ipp_state_free(st); return rc; }
-    } else if (!st->fold_generators && n >= 16 && st->ctx->tuning.small_msm) {
+    } else if (digits) {
         // ... but every round is a small MSM over the SAME 2n + 1 points: their digit multiples, once (one ~0.1 ms launch for lg n rounds
         // that each lose the per-lane doubling chain; same-box A/B: n = 64 2.24-2.51 -> 2.04-2.07 ms per proof, n = 128 2.94-3.26 ->
         // 2.38-2.42, n = 16 1.35-1.60 -> 1.28-1.30; at n = 4 the launch costs more than two rounds save: 0.66 -> 0.72)

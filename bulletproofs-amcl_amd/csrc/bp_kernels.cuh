@@ -786,6 +786,10 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
 
 // ---------------------------------------------------------------------------------------------- small MSM (n <= kSmallMsmMax)
 constexpr size_t kSmallMsmMax = 512;   // above this the bucket pipeline wins (scripts/time_pair.py)
+constexpr size_t kSmallDigitMax = 8193;  // ... unless the digit multiples of the points are at hand (k_digit_table_build): a lane then pays one
+                                         // addition per term, and above kSmallMsmMax terms a window's terms are dealt to TWO blocks (64 windows x
+                                         // 2 scalar sets x 2 = one block per CU), each leaving its own record at the window's bit position:
+                                         // 2n + 1 = 8193 terms are 16 serial additions + the 8-level tree
 // The bucket pipeline is a dozen dependent launches; for the 2n + 1 <= 256 terms of a small inner-product round most of its
 // time is launch gaps and the depth of the bucket reduce.  Here one block per window does the whole job in one launch: lane t
 // multiplies point t by its signed digit of this window (|digit| <= 2^(cw-1): a few doublings and mixed additions), then an LDS
@@ -823,7 +827,8 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
     const int w = blockIdx.x, wps = tab.W / tab.nsets, set = w / wps;
     const int cw = tab.cw[w], off = tab.off[w];
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
-    for (uint32_t t = threadIdx.x; t < n; t += kBlock) {      // kSmallMsmMax / kBlock terms per lane at most
+    // grid.y blocks share a window's terms (block b: terms b * 256 + lane, stride 256 * grid.y) and leave one record each
+    for (uint32_t t = blockIdx.y * kBlock + threadIdx.x; t < n; t += kBlock * gridDim.y) {      // kSmallMsmMax / kBlock terms per lane at most (16 with mult)
         uint64_t q[4];
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
         int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
@@ -845,7 +850,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         mine = xyzz_lazy_add(mine, acc);
     }
     mine = block_tree_sum<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
-    if (threadIdx.x == 0) window_sum[tab.roff[w]] = xyzz_lazy_pack(mine);
+    if (threadIdx.x == 0) window_sum[tab.roff[w] + blockIdx.y] = xyzz_lazy_pack(mine);
 }
 
 // ---------------------------------------------------------------------------------------------- device tail (optional)
