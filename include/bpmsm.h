@@ -86,7 +86,8 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_TILE 1        /* scalars per block of the binning passes: a multiple of 256 in [256, 16384] */
 #define BP_TUNE_REDUCE_M 2    /* buckets per bucket-reduce thread: a power of two in [1, 16384] */
 #define BP_TUNE_TASK_TARGET 3 /* number of tasks the accumulate kernel aims at: [1024, 2^28] */
-#define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 512 terms */
+#define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 512 terms (and, inside an inner-product proof of 16 .. 4096
+                               * generators, for its rounds of up to 8193 terms over precomputed digit multiples) */
 #define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
 /* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
@@ -293,7 +294,10 @@ typedef struct bp_ipp_state bp_ipp_state;
  * each round's L and R are MSMs over the original resident [G | H | Q] with per-generator coefficient vectors (four Fr
  * multiplications per generator per round).  1: the reference's shape -- G and H are folded in place every round by a
  * batched G1::binary_scalar_mul kernel (src/ipp.rs:119,125,185,187), a 255-step serial chain per element.  Both give
- * bit-identical L, R, a, b. */
+ * bit-identical L, R, a, b.
+ * Mode 0 keeps per-state tables beside [G | H | Q]: for 16 <= n <= 4096 the multiples 1P .. 8P of the 2n + 1 points (8 x 192 B per
+ * point, one launch inside state_create) so that a round is ONE kernel launch; above that, when G and H carry window tables
+ * (bp_g1vec_precompute), their concatenation.  Freed with the state. */
 int bp_ctx_set_ipp_fold_generators(bp_ctx* ctx, int on);
 int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* Q_le, const bp_frvec* G_factors,
                         const bp_frvec* H_factors, const bp_frvec* a, const bp_frvec* b, bp_ipp_state** out);
