@@ -216,7 +216,9 @@ def commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b):
     return pts.multi_scalar_mul_var_time(sc)
 
 
-@pytest.mark.parametrize("name,n,unit_gf", [("bls12_381", 64, True), ("bls12_381", 32, False), ("bn254", 64, True), ("bn254", 256, False)])
+# (n = 16 .. 4096: rounds on the single-launch path over the state's digit multiples; above 255 two blocks per window)
+@pytest.mark.parametrize("name,n,unit_gf", [("bls12_381", 64, True), ("bls12_381", 32, False), ("bn254", 64, True), ("bn254", 256, False),
+                                            ("bls12_381", 8, False), ("bls12_381", 16, False), ("bls12_381", 512, False), ("bls12_381", 2048, True), ("bn254", 1024, False)])
 def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf, prover_mode):
     """BASELINE config 1 shape (n = 64): GPU proof bit-for-bit equal to the oracle's, accepted by both verifiers."""
     ctx = ctxs[name]
