@@ -437,4 +437,116 @@ template <class C> BP_HD XyzzLazy<C> xyzz_lazy_unpack(const XyzzPacked<C>& p) {
     return r;
 }
 
+// ----------------------------------------------------------------------------------------------- one addition on FOUR lanes
+// The tree sums that end every latency-bound kernel (k_small_msm, the heavy-bucket combine) add ever fewer points per level while
+// the block's other lanes idle, and a dependent addition is ~5 300 wave instructions (17 us at one wave per SIMD) whether one lane
+// or 64 run it.  Here the four lanes of a quad share ONE addition slot[ia] += slot[ib] of packed lazy points in LDS: the 14 products
+// of add-2008-s run as four rounds of one product per lane,
+//     round 1   U1 = X1 ZZ2        U2 = X2 ZZ1         S1 = Y1 ZZZ2        S2 = Y2 ZZZ1
+//     round 2   PP = P^2           RR = R^2            ZZ12 = ZZ1 ZZ2      ZZZ12 = ZZZ1 ZZZ2          (P = U2 - U1, R = S2 - S1)
+//     round 3   PPP = P PP         Q = U1 PP           ZZ3 = ZZ12 PP       --
+//     round 4   ZZZ3 = ZZZ12 PPP   T2 = (-S1) PPP      T1 = R (Q - X3)     --                          (X3 = RR - PPP - 2Q, Y3 = T1 + T2)
+// with results handed between lanes by quad-permute DPP moves and per-lane operands chosen by bit-select with lane masks: ~1 900
+// wave instructions instead of ~5 300.  Same bounded domain as xyzz_lazy_add (every product within kMaxProd, X3 < 8p, Y3 < 4p,
+// ZZ3, ZZZ3 < 2p), same results mod p; the rare cases (an identity operand, P = 0: doubling or cancellation) are decided per quad.
+// All four lanes of the quad must be active and agree on (ia, ib).  Device only.
+#if defined(__HIPCC__)
+// lane l of a quad reads lane quad_perm[l] (CTRL = the four 2-bit selectors).  The empty asm pins the result in a VGPR: without it the
+// compiler's DPP combiner folds the move into the consuming add / sub and -- when both operands of a subtraction are DPP moves of the
+// same register -- produces wrong lanes (hipcc 7.2, gfx950; probe: perm[1,3,1,3](x) - perm[0,2,0,2](x) gave 3 0 -3 -6 for 3 3 3 3).
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm_u32(uint32_t v) {
+    int r = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    asm volatile("" : "+v"(r));
+    return (uint32_t)r;
+}
+template <int CTRL, class P, int B> __device__ __forceinline__ FeB<P, B> feb_quad_perm(const FeB<P, B>& a) {
+    FeB<P, B> r;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) r.v[i] = quad_perm_u32<CTRL>(a.v[i]);
+    return r;
+}
+// m = all ones: a, m = 0: b (per lane)
+template <int B, class P, int B1, int B2> __device__ __forceinline__ FeB<P, B> feb_select(uint32_t m, const FeB<P, B1>& a, const FeB<P, B2>& b) {
+    static_assert(B >= B1 && B >= B2, "the selection carries the larger bound");
+    FeB<P, B> r;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) r.v[i] = (a.v[i] & m) | (b.v[i] & ~m);
+    return r;
+}
+constexpr int kQuadBcast0 = 0x00, kQuadBcast1 = 0x55, kQuadBcast2 = 0xaa, kQuadBcast3 = 0xff;   // quad_perm:[k,k,k,k]
+constexpr int kQuadPerm1313 = 1 | (3 << 2) | (1 << 4) | (3 << 6), kQuadPerm0202 = 0 | (2 << 2) | (0 << 4) | (2 << 6);
+
+template <class C>
+__device__ __forceinline__ void xyzz_lazy_add_quad(XyzzPacked<C>* slots, int ia, int ib, int q) {
+    using Fp = typename C::Fp;
+    constexpr int NW = Fp::NW;
+    uint32_t* wa = (uint32_t*)&slots[ia];
+    const uint32_t* wb = (const uint32_t*)&slots[ib];
+    const uint32_t m0 = q == 0 ? ~0u : 0u, m1 = q == 1 ? ~0u : 0u, m2 = q == 2 ? ~0u : 0u, m01 = q < 2 ? ~0u : 0u;
+    // fields: 0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ.  Round-1 operands of lane q, and the round-2 operands of lanes 2, 3 (lanes 0, 1 load lane 2's)
+    const int fa1 = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3;          // of a:  X1   ZZ1   Y1    ZZZ1
+    const int fb1 = q == 0 ? 2 : q == 1 ? 0 : q == 2 ? 3 : 1;          // of b:  ZZ2  X2    ZZZ2  Y2
+    const int f2 = q == 3 ? 3 : 2;                                     // ZZ (lanes 0 .. 2), ZZZ (lane 3)
+    FeB<Fp, 8> A1, B1;
+    FeB<Fp, 2> A2, B2;
+    { Fe<Fp> t = fe_unpack_words<Fp>(wa + fa1 * NW); for (int i = 0; i < Fp::NL; i++) A1.v[i] = t.v[i]; }
+    { Fe<Fp> t = fe_unpack_words<Fp>(wb + fb1 * NW); for (int i = 0; i < Fp::NL; i++) B1.v[i] = t.v[i]; }
+    { Fe<Fp> t = fe_unpack_words<Fp>(wa + f2 * NW); for (int i = 0; i < Fp::NL; i++) A2.v[i] = t.v[i]; }
+    { Fe<Fp> t = fe_unpack_words<Fp>(wb + f2 * NW); for (int i = 0; i < Fp::NL; i++) B2.v[i] = t.v[i]; }
+    // identity operands (ZZ = 0 exactly): lanes 0 .. 2 hold ZZ1, ZZ2 in A2, B2
+    uint32_t za = 0, zb = 0;
+#pragma unroll
+    for (int i = 0; i < Fp::NL; i++) { za |= A2.v[i]; zb |= B2.v[i]; }
+    za = quad_perm_u32<kQuadBcast0>(za);
+    zb = quad_perm_u32<kQuadBcast0>(zb);
+    if (zb == 0) return;                                               // a + identity
+    if (za == 0) {                                                     // identity + b: lane q copies field q
+        for (int i = 0; i < NW; i++) wa[q * NW + i] = wb[q * NW + i];
+        return;
+    }
+    // ---- round 1
+    const FeB<Fp, 2> r1 = feb_mul(A1, B1);                             // U1 | U2 | S1 | S2     (A1 is X or Y (< 8p), or ZZ / ZZZ; B1 likewise: <= 8 * 8)
+    const FeB<Fp, 2> hi = feb_quad_perm<kQuadPerm1313>(r1), lo = feb_quad_perm<kQuadPerm0202>(r1);
+    const FeB<Fp, 4> D = feb_sub<2>(hi, lo);                           // lanes 0, 2: P = U2 - U1; lanes 1, 3: R = S2 - S1
+    uint32_t dz = feb_is_zero_mod_p(D) ? 1u : 0u;
+    const uint32_t pz = quad_perm_u32<kQuadBcast0>(dz);
+    if (pz) {                                                          // same x: doubling or cancellation -- lane 0 alone, the one-lane formulas
+        if (q == 0) slots[ia] = xyzz_lazy_pack(xyzz_lazy_add(xyzz_lazy_unpack(slots[ia]), xyzz_lazy_unpack(slots[ib])));
+        return;
+    }
+    // ---- round 2
+    const FeB<Fp, 4> a2 = feb_select<4>(m01, D, A2), b2 = feb_select<4>(m01, D, B2);
+    const FeB<Fp, 2> r2 = feb_mul(a2, b2);                             // PP | RR | ZZ12 | ZZZ12
+    const FeB<Fp, 2> PP = feb_quad_perm<kQuadBcast0>(r2);
+    // ---- round 3
+    const FeB<Fp, 2> U1 = feb_quad_perm<kQuadBcast0>(r1);
+    const FeB<Fp, 4> a3 = feb_select<4>(m0, D, feb_select<2>(m1, U1, r2));
+    const FeB<Fp, 2> r3 = feb_mul(a3, PP);                             // PPP | Q | ZZ3 | (unused)
+    const FeB<Fp, 2> PPP = feb_quad_perm<kQuadBcast0>(r3), Q = feb_quad_perm<kQuadBcast1>(r3), RR = feb_quad_perm<kQuadBcast1>(r2);
+    const FeB<Fp, 8> X3 = feb_sub<2>(feb_sub<2>(feb_sub<2>(RR, PPP), Q), Q);
+    const FeB<Fp, 10> QX = feb_sub<8>(Q, X3);
+    // ---- round 4
+    const FeB<Fp, 2> Z12 = feb_quad_perm<kQuadBcast3>(r2), S1 = feb_quad_perm<kQuadBcast2>(r1);
+    const FeB<Fp, 4> R = feb_quad_perm<kQuadBcast1>(D);
+    const FeB<Fp, 4> a4 = feb_select<4>(m0, Z12, feb_select<4>(m1, feb_neg<2>(S1), R));
+    const FeB<Fp, 10> b4 = feb_select<10>(m2, QX, PPP);
+    const FeB<Fp, 2> r4 = feb_mul(a4, b4);                             // ZZZ3 | T2 | T1 | (unused)
+    const FeB<Fp, 2> T2 = feb_quad_perm<kQuadBcast1>(r4);
+    const FeB<Fp, 4> Y3 = feb_add(r4, T2);                             // lane 2: T1 + T2
+    // ---- the result, field by field: lane 0 X3 and ZZZ3, lane 2 Y3 and ZZ3
+    if (q == 0) {
+        XyzzLazy<C> t;                                                 // (packing X needs the conditional 4p of xyzz_lazy_pack: reuse it on a full record)
+        t.x = X3; t.y = feb_widen<4>(r4); t.zz = r4; t.zzz = r4; t.inf = false;
+        const XyzzPacked<C> pk = xyzz_lazy_pack(t);
+        for (int i = 0; i < NW; i++) { wa[i] = pk.x.w[i]; wa[3 * NW + i] = pk.zzz.w[i]; }
+    } else if (q == 2) {
+        Fe<Fp> t;
+        for (int i = 0; i < Fp::NL; i++) t.v[i] = Y3.v[i];
+        fe_pack_words<Fp>(wa + NW, t);
+        for (int i = 0; i < Fp::NL; i++) t.v[i] = r3.v[i];
+        fe_pack_words<Fp>(wa + 2 * NW, t);
+    }
+}
+#endif
+
 }  // namespace bp

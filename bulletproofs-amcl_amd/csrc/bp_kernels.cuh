@@ -548,6 +548,25 @@ __device__ __forceinline__ XyzzLazy<C> block_tree_sum(XyzzLazy<C> mine, XyzzPack
     return mine;
 }
 
+// The same tree with every addition shared by the four lanes of a quad (xyzz_lazy_add_quad, bp_curve.cuh): a level of s additions
+// keeps 4 s lanes busy for ~1 900 wave instructions instead of s lanes for ~5 300 (levels of more than 64 additions run in rounds of
+// 64).  Result valid in thread 0.
+template <class C>
+__device__ __forceinline__ XyzzLazy<C> block_tree_sum_quad(XyzzLazy<C> mine, XyzzPacked<C>* lds, int active = kBlock) {
+    lds[threadIdx.x] = xyzz_lazy_pack(mine);
+    __syncthreads();
+    int s0 = kBlock / 2;
+    while (s0 >= active && s0 > 0) s0 >>= 1;   // largest stride with a live partner
+    const int quad = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3;
+#pragma unroll 1
+    for (int s = s0; s > 0; s >>= 1) {
+#pragma unroll 1
+        for (int i = quad; i < s; i += kBlock / 4) xyzz_lazy_add_quad<C>(lds, i, i + s, q);
+        __syncthreads();
+    }
+    return xyzz_lazy_unpack(lds[0]);
+}
+
 // Heavy buckets (more than kLightMax tasks) are folded in two stages so that one bucket holding most of the points -- 0/1
 // scalars, the a_L / a_R commitments of a range proof, put half of all points into ONE bucket: 4096 task sums at n = 2^16 --
 // is a tree over many blocks instead of one long chain (one wave: 64 + 6 dependent additions, 1.23 ms; chunked: 8 + 1 + 4):
@@ -622,7 +641,7 @@ __global__ void __launch_bounds__(kBlock) k_combine_heavy(const uint32_t* __rest
         XyzzLazy<C> mine = xyzz_lazy_inf<C>();
         for (uint32_t k = threadIdx.x; k < nch; k += kBlock) mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(tsum[t0 + k * kBlock]));
         __syncthreads();   // all chunk sums read before tsum[t0] is overwritten
-        mine = block_tree_sum<C>(mine, lds, nch < (uint32_t)kBlock ? (int)nch : kBlock);
+        mine = block_tree_sum_quad<C>(mine, lds, nch < (uint32_t)kBlock ? (int)nch : kBlock);
         if (threadIdx.x == 0) tsum[t0] = xyzz_lazy_pack(mine);
         __syncthreads();
     }
@@ -647,14 +666,24 @@ __device__ __forceinline__ void plane_tree(XyzzPacked<C>* lds, int live, int pit
 #pragma unroll 1
     for (int s = live >> 1; s >= 1; s >>= 1, born += planes ? 1 : 0) {
         const int nitems = (nplain + 1 + born) * s;
+        if (nitems <= kBlock / 2) {
+            // few items: four lanes per addition (xyzz_lazy_add_quad: ~1 900 instead of ~5 300 wave instructions per round of 64 items)
 #pragma unroll 1
-        for (int q = (int)threadIdx.x; q < nitems; q += kBlock) {
-            const int u = q / s, i = q - u * s;
-            // u = 0: X itself; 1 .. born: the plane born u steps ago sits at stride live >> u; then the plain arrays
-            const int base = u == 0 ? 0 : u <= born ? (live >> u) : (u - born) * pitch;
-            XyzzLazy<C> a = xyzz_lazy_unpack(lds[base + i]);
-            a = xyzz_lazy_add(a, xyzz_lazy_unpack(lds[base + i + s]));
-            lds[base + i] = xyzz_lazy_pack(a);
+            for (int it = (int)threadIdx.x >> 2; it < nitems; it += kBlock / 4) {
+                const int u = it / s, i = it - u * s;
+                const int base = u == 0 ? 0 : u <= born ? (live >> u) : (u - born) * pitch;
+                xyzz_lazy_add_quad<C>(lds, base + i, base + i + s, (int)threadIdx.x & 3);
+            }
+        } else {
+#pragma unroll 1
+            for (int q = (int)threadIdx.x; q < nitems; q += kBlock) {
+                const int u = q / s, i = q - u * s;
+                // u = 0: X itself; 1 .. born: the plane born u steps ago sits at stride live >> u; then the plain arrays
+                const int base = u == 0 ? 0 : u <= born ? (live >> u) : (u - born) * pitch;
+                XyzzLazy<C> a = xyzz_lazy_unpack(lds[base + i]);
+                a = xyzz_lazy_add(a, xyzz_lazy_unpack(lds[base + i + s]));
+                lds[base + i] = xyzz_lazy_pack(a);
+            }
         }
         __syncthreads();
     }
@@ -849,7 +878,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         }
         mine = xyzz_lazy_add(mine, acc);
     }
-    mine = block_tree_sum<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
+    mine = block_tree_sum_quad<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
     if (threadIdx.x == 0) window_sum[tab.roff[w] + blockIdx.y] = xyzz_lazy_pack(mine);
 }
 
