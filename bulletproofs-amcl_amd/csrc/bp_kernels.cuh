@@ -578,16 +578,16 @@ __device__ __forceinline__ XyzzLazy<C> block_tree_sum_quad(XyzzLazy<C> mine, Xyz
 // bucket of bit scalars -- down to 4 lanes when there are thousands of them (256 distinct scalar values: 4096 buckets of 64 task sums,
 // 1.9 ms block-per-chunk, 16 rounds of a 6-level tree on 64 of 256 lanes; a window-multiples table at c = 14: 16 384 buckets of
 // 10).  Lane l of the group first adds the task sums l, l + G, ... of its chunk (a serial chain), then the group's tree runs over
-// the G partial sums.  ONE addition site serves both phases (code size: see plane_tree).
+// the G partial sums, four lanes per addition (xyzz_lazy_add_quad).
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_combine_chunks(const uint2* __restrict__ chunks, const uint32_t* __restrict__ nchunks,
                                                            const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ntasks,
                                                            XyzzPacked<C>* __restrict__ tsum) {
     __shared__ XyzzPacked<C> lds[kBlock];
-    __shared__ uint32_t s_most;
+    __shared__ uint32_t s_most, s_live[kBlock / 4];
     const uint32_t count = *nchunks;
-    uint32_t G = kBlock, lgG = 8;
-    while (G > 4 && (uint64_t)count > (uint64_t)gridDim.x * (kBlock / G)) { G >>= 1; lgG--; }
+    uint32_t G = kBlock;
+    while (G > 4 && (uint64_t)count > (uint64_t)gridDim.x * (kBlock / G)) G >>= 1;
     const uint32_t gpb = kBlock / G, lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     for (uint32_t c0 = blockIdx.x * gpb; c0 < count; c0 += gridDim.x * gpb) {         // block-uniform bounds
         const uint32_t c = c0 + grp;
@@ -600,31 +600,31 @@ __global__ void __launch_bounds__(kBlock) k_combine_chunks(const uint2* __restri
         }
         if (threadIdx.x == 0) s_most = 0;
         __syncthreads();
-        if (lane == 0 && cnt) atomicMax(&s_most, cnt);
+        if (lane == 0) { s_live[grp] = cnt < G ? cnt : G; if (cnt) atomicMax(&s_most, cnt); }      // lanes of the group that will hold a partial sum
         __syncthreads();
         const uint32_t nser = (s_most + G - 1) / G;                 // serial steps of the longest chunk of this round (>= 1)
-        const uint32_t live = cnt < G ? cnt : G;                    // lanes of the group that hold a partial sum
+        // serial phase: lane l adds the task sums l, l + G, ... of its chunk
         XyzzLazy<C> mine = lane < cnt ? xyzz_lazy_unpack(tsum[first + lane]) : xyzz_lazy_inf<C>();
 #pragma unroll 1
-        for (uint32_t t = 1; t < nser + lgG; t++) {
-            XyzzLazy<C> b = xyzz_lazy_inf<C>();
-            bool have;
-            if (t < nser) {                                         // serial phase: my next task sum
-                const uint32_t k = lane + t * G;
-                have = k < cnt;
-                if (have) b = xyzz_lazy_unpack(tsum[first + k]);
-            } else {                                                // tree phase, stride G / 2, G / 4, ..., 1
-                const uint32_t st = G >> (t - nser + 1);
-                lds[threadIdx.x] = xyzz_lazy_pack(mine);
-                __syncthreads();
-                have = lane < st && lane + st < live;
-                if (have) b = xyzz_lazy_unpack(lds[threadIdx.x + st]);
-                __syncthreads();                                    // read before the next level overwrites
-            }
-            if (have) mine = xyzz_lazy_add(mine, b);
+        for (uint32_t t = 1; t < nser; t++) {
+            const uint32_t k = lane + t * G;
+            if (k < cnt) mine = xyzz_lazy_add(mine, xyzz_lazy_unpack(tsum[first + k]));
         }
-        if (lane == 0 && cnt) tsum[first] = xyzz_lazy_pack(mine);
-        __syncthreads();                                            // s_most and lds are reused by the next round
+        // tree phase over the group's partial sums, every addition on four lanes (xyzz_lazy_add_quad): item (g, i) is
+        // slot[g G + i] += slot[g G + i + st], present when lane i + st of group g holds a sum
+        lds[threadIdx.x] = xyzz_lazy_pack(mine);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t st = G >> 1; st >= 1; st >>= 1) {
+#pragma unroll 1
+            for (uint32_t it = threadIdx.x >> 2; it < gpb * st; it += kBlock / 4) {
+                const uint32_t g = it / st, i = it - g * st;
+                if (i + st < s_live[g]) xyzz_lazy_add_quad<C>(lds, (int)(g * G + i), (int)(g * G + i + st), (int)(threadIdx.x & 3));
+            }
+            __syncthreads();
+        }
+        if (lane == 0 && cnt) tsum[first] = lds[threadIdx.x];
+        __syncthreads();                                            // s_most, s_live and lds are reused by the next round
     }
 }
 
