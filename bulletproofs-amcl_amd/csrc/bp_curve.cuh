@@ -482,7 +482,9 @@ __device__ __forceinline__ void xyzz_lazy_add_quad(XyzzPacked<C>* slots, int ia,
     constexpr int NW = Fp::NW;
     uint32_t* wa = (uint32_t*)&slots[ia];
     const uint32_t* wb = (const uint32_t*)&slots[ib];
-    const uint32_t m0 = q == 0 ? ~0u : 0u, m1 = q == 1 ? ~0u : 0u, m2 = q == 2 ? ~0u : 0u, m01 = q < 2 ? ~0u : 0u;
+    uint32_t m0 = q == 0 ? ~0u : 0u, m1 = q == 1 ? ~0u : 0u, m2 = q == 2 ? ~0u : 0u, m01 = q < 2 ? ~0u : 0u;
+    // (opaque to the compiler: it otherwise recognises the selections below and emits v_cndmask_b32, ~5x the issue cost of the and / or pair)
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m01));
     // fields: 0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ.  Round-1 operands of lane q, and the round-2 operands of lanes 2, 3 (lanes 0, 1 load lane 2's)
     const int fa1 = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3;          // of a:  X1   ZZ1   Y1    ZZZ1
     const int fb1 = q == 0 ? 2 : q == 1 ? 0 : q == 2 ? 3 : 1;          // of b:  ZZ2  X2    ZZZ2  Y2

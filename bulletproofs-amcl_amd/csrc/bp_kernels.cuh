@@ -857,6 +857,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
     const int cw = tab.cw[w], off = tab.off[w];
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
     // grid.y blocks share a window's terms (block b: terms b * 256 + lane, stride 256 * grid.y) and leave one record each
+#pragma unroll 1
     for (uint32_t t = blockIdx.y * kBlock + threadIdx.x; t < n; t += kBlock * gridDim.y) {      // kSmallMsmMax / kBlock terms per lane at most (16 with mult)
         uint64_t q[4];
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
