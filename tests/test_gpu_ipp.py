@@ -235,6 +235,36 @@ def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf, prover_mode):
                         proof.L, proof.R, proof.lg_n) == 0
 
 
+@pytest.mark.parametrize("name,n", [("bls12_381", 32), ("bn254", 64), ("bls12_381", 1024)])
+def test_ipp_degenerate_generators_vs_oracle(bp, ctxs, name, n):
+    """Generators with structure the digit-multiples table and the four-lane tree must survive: identity points, a repeated point,
+    a point and its negative, a generator equal to Q -- and scalar vectors with zeros and repeats.  Proof bytes = the oracle's."""
+    ctx = ctxs[name]
+    cid = ctx.curve
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 9100 + n, unit_gf=False)
+    pb = ctx.point_bytes
+    g, h = bytearray(Gv.to_bytes()), bytearray(Hv.to_bytes())
+    P0 = bytes(g[0:pb])
+    negP0 = O.g1_mul(cid, (ctx.r - 1).to_bytes(32, "little"), P0)
+    g[pb * 1:pb * 2] = bytes(pb)                     # identity
+    g[pb * 2:pb * 3] = P0                            # repeated
+    g[pb * 3:pb * 4] = negP0                         # P and -P in one vector
+    h[pb * 0:pb * 1] = P0                            # shared between G and H
+    h[pb * 5:pb * 6] = bytes(pb)
+    h[pb * 6:pb * 7] = Q                             # a generator equal to Q
+    Gv = bp.G1Vector.from_bytes(ctx, bytes(g), n)
+    Hv = bp.G1Vector.from_bytes(ctx, bytes(h), n)
+    ab, bb = bytearray(a.to_bytes()), bytearray(b.to_bytes())
+    ab[32 * 4:32 * 5] = bytes(32); ab[32 * 6:32 * 7] = ab[0:32]
+    bb[32 * 0:32 * 1] = bytes(32); bb[32 * 9:32 * 10] = bb[32:64]
+    a, b = bp.FieldElementVector.from_bytes(ctx, bytes(ab), n), bp.FieldElementVector.from_bytes(ctx, bytes(bb), n)
+    proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes(), n)
+    assert rc == 0 and (proof.L, proof.R, proof.a, proof.b) == want
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+
+
 @pytest.mark.parametrize("name,n,c", [("bls12_381", 256, 0), ("bls12_381", 1024, 11), ("bn254", 512, 16), ("bn254", 2048, 9)])
 def test_ipp_with_precomputed_generators(bp, ctxs, name, n, c):
     """bp_g1vec_precompute on G and H: every round's L / R is a merged-window MSM over [G | H | Q] rows -- the proof must be the
