@@ -14,7 +14,7 @@ struct MsmGeom {
     WinTab tab;      // W windows of nearly equal width covering fr_bits + 1 bits
     uint32_t m;      // buckets per reduce thread (a power of two; windows with fewer buckets use their bucket count)
     bool small;      // n <= kSmallMsmMax: the single-launch path, one record per window
-    int small_blocks; // ... per block of the window: 2 above kSmallMsmMax terms (only with the points' digit multiples), else 1
+    int small_blocks; // ... per block of the window: 2 above 512 terms, else 1
     bool merged;     // MSM over a window-multiples table: tab describes the digit windows, tabv the merged buckets (one "window" per scalar set)
     WinTab tabv;     // merged only: the view the kernels after the coarse scatter run with (k_fine_place .. k_window_sums)
     // tail records handed to the host: record r carries weight 2^rpos[r] (bp_host_tail.hpp folds any such list)
@@ -110,7 +110,7 @@ static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets
     // a record layout across shards fix the window width (bp_ctx_set_window_bits / bp_msm_g1_multi), and a fixed width always means
     // the pipeline's layout -- a 5-point shard beside a 2^20-point one then folds with it.
     g.small = n <= small_max && small_ok && c_override <= 0;       // small_max: kSmallDigitMax when the caller holds the points' digit multiples
-    g.small_blocks = g.small && n > kSmallMsmMax ? 2 : 1;
+    g.small_blocks = g.small && n > 512 ? 2 : 1;                    // more than two terms per lane: two blocks per window, a record each
     // k_small_msm (n <= kSmallMsmMax): each lane multiplies by its digit, so narrow windows shorten the chain; below c = 4 the
     // extra windows cost more on the host (one addition per window in the tail) than they save on the device
     if (c_override <= 0 && g.small && c > kSmallDigitBits) c = kSmallDigitBits;
@@ -254,7 +254,7 @@ struct Impl {
             if (tm) for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st));
             // the multiples only when they are this vector's and cover the digits of this geometry
             const XyzzPacked<C>* mult = dm && dm->n == n && g.c <= dm->c ? (const XyzzPacked<C>*)dm->d : nullptr;
-            if (g.small_blocks > 1 && !mult) return BP_ERR_ARG;    // (msm_geom only goes above kSmallMsmMax for a vector whose multiples it was shown)
+            //if (g.small_blocks > 1 && !mult) return BP_ERR_ARG;    // (msm_geom only goes above kSmallMsmMax for a vector whose multiples it was shown)
             hipLaunchKernelGGL(k_small_msm<C>, dim3(W, g.small_blocks), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p, mult);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
             if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));

@@ -814,11 +814,13 @@ __global__ void __launch_bounds__(kBlock) k_bucket_reduce(const XyzzPacked<C>* _
 }
 
 // ---------------------------------------------------------------------------------------------- small MSM (n <= kSmallMsmMax)
-constexpr size_t kSmallMsmMax = 512;   // above this the bucket pipeline wins (scripts/time_pair.py)
+constexpr size_t kSmallMsmMax = 1536;   // above this the bucket pipeline wins (512 until the tree's additions ran on four lanes each; same-box
+                                        // A/B after that: 1024 terms 0.475 -> 0.365 ms single-launch, 2048 terms 0.48 = 0.47 ms; IPP verify at n = 256 / 512
+                                        // -- 529 / 1043 terms -- 0.51 -> 0.43 / 0.55 -> 0.50 ms).  More than 512 terms: two blocks per window.
 constexpr size_t kSmallDigitMax = 8193;  // ... unless the digit multiples of the points are at hand (k_digit_table_build): a lane then pays one
-                                         // addition per term, and above kSmallMsmMax terms a window's terms are dealt to TWO blocks (64 windows x
-                                         // 2 scalar sets x 2 = one block per CU), each leaving its own record at the window's bit position:
-                                         // 2n + 1 = 8193 terms are 16 serial additions + the 8-level tree
+                                         // addition per term.  Above 512 terms a window's terms are dealt to TWO blocks (64 windows x 2 scalar
+                                         // sets x 2 = one block per CU), each leaving its own record at the window's bit position: 2n + 1 = 8193
+                                         // terms are 16 serial additions + the 8-level tree
 // The bucket pipeline is a dozen dependent launches; for the 2n + 1 <= 256 terms of a small inner-product round most of its
 // time is launch gaps and the depth of the bucket reduce.  Here one block per window does the whole job in one launch: lane t
 // multiplies point t by its signed digit of this window (|digit| <= 2^(cw-1): a few doublings and mixed additions), then an LDS

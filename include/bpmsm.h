@@ -86,7 +86,7 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_TILE 1        /* scalars per block of the binning passes: a multiple of 256 in [256, 16384] */
 #define BP_TUNE_REDUCE_M 2    /* buckets per bucket-reduce thread: a power of two in [1, 16384] */
 #define BP_TUNE_TASK_TARGET 3 /* number of tasks the accumulate kernel aims at: [1024, 2^28] */
-#define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 512 terms (and, inside an inner-product proof of 16 .. 4096
+#define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 1536 terms (and, inside an inner-product proof of 16 .. 4096
                                * generators, for its rounds of up to 8193 terms over precomputed digit multiples) */
 #define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
@@ -217,7 +217,7 @@ int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, s
 int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32);
 /* A record block holds nrec records and its header; record r carries weight 2^pos[r]:  result = sum_r 2^pos[r] * record[r].
  * Since round 3 a window contributes one record for its plain weighted sum plus one per bit of the reduce-thread index (bit planes:
- * 13 per window at n = 2^20); the single-launch path for n <= 512 -- taken only when no window width is fixed -- has one per window.
+ * 13 per window at n = 2^20); the single-launch path for n <= 1536 -- taken only when no window width is fixed -- has one per window (two above 512 terms).
  * nrec = bp_msm_window_records() - 1; pos_out needs room for 4096 entries. */
 int bp_msm_record_positions(int curve_id, size_t n, int window_bits, int* nrec_out, uint16_t* pos_out);
 /* Record-block helpers for hosts that build or check blocks themselves (tests, aggregators): an affine point as a window
