@@ -121,7 +121,8 @@ def test_fixed_base_and_scalar_mul(bp, ctxs, name):
 
 
 @pytest.mark.parametrize("name", CURVES)
-@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 33, 1000, 4097, 70000])
+# (512 / 513: one / two blocks per window of the single-launch path; 1536 / 1537: its limit, the bucket pipeline beyond)
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 33, 512, 513, 1000, 1536, 1537, 4097, 70000])
 def test_msm_random_vs_oracle(bp, ctxs, name, n):
     ctx = ctxs[name]
     ks = O.random_scalars(ctx.curve, 100 + n, n)
@@ -134,7 +135,7 @@ def test_msm_random_vs_oracle(bp, ctxs, name, n):
 
 
 @pytest.mark.parametrize("name", CURVES)
-@pytest.mark.parametrize("n", [1, 3, 129, 5000, 70000])
+@pytest.mark.parametrize("n", [1, 3, 129, 513, 1536, 1537, 5000, 70000])
 def test_msm_pair_equals_two_msms(bp, ctxs, name, n):
     ctx = ctxs[name]
     pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, O.random_scalars(ctx.curve, 50 + n, n), n))
