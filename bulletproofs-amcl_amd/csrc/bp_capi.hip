@@ -253,9 +253,12 @@ struct Impl {
         if (g.small) {   // one launch: block per window, lane per term (k_small_msm)
             if (tm) for (int e = 0; e < 6; e++) HIPCHK(hipEventRecord(ctx->ev[e], st));
             // the multiples only when they are this vector's and cover the digits of this geometry
-            const XyzzPacked<C>* mult = dm && dm->n == n && g.c <= dm->c ? (const XyzzPacked<C>*)dm->d : nullptr;
-            //if (g.small_blocks > 1 && !mult) return BP_ERR_ARG;    // (msm_geom only goes above kSmallMsmMax for a vector whose multiples it was shown)
-            hipLaunchKernelGGL(k_small_msm<C>, dim3(W, g.small_blocks), dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, (XyzzPacked<C>*)ctx->window_sum.p, mult);
+            const void* mult = dm && dm->n == n && g.c <= dm->c ? dm->d : nullptr;
+            const dim3 grid(W, g.small_blocks);
+            auto* ws = (XyzzPacked<C>*)ctx->window_sum.p;
+            if (!mult) hipLaunchKernelGGL((k_small_msm<C, 0>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult);
+            else if (dm->affine) hipLaunchKernelGGL((k_small_msm<C, 2>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult);
+            else hipLaunchKernelGGL((k_small_msm<C, 1>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
             if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
             HIPCHK(hipGetLastError());
@@ -959,6 +962,10 @@ int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
     case BP_TUNE_SMALL_MSM:
         if (value > 1) return BP_ERR_ARG;
         ctx->tuning.small_msm = value != 0;
+        return BP_OK;
+    case BP_TUNE_COMPACT_AT:    // 0 automatic, 1 never, else the live length (a power of two whose rounds are single launches) to compact at
+        if (value > 1 && (value < 16 || (value & (value - 1)) || 2 * (size_t)value + 1 > kSmallDigitMax)) return BP_ERR_ARG;
+        ctx->tuning.compact_at = (uint32_t)value;
         return BP_OK;
     default:
         return BP_ERR_ARG;

@@ -8,6 +8,7 @@
 
 #include "bp_internal.hpp"
 #include "bp_ipp.cuh"
+#include "bp_compact.cuh"
 #include "bp_merlin.hpp"
 #include "bp_host_tail.hpp"
 
@@ -32,6 +33,13 @@ struct bp_ipp_state {
     bool fold_generators;
     void *Pall, *cG, *cH, *sL, *sR;
     bp_g1table* table;       // window multiples of [G | H | Q] when G and H carry tables (bp_g1vec_precompute): every round's MSM is merged-window
+    // generator compaction (bp_compact.cuh): once the live length has shrunk to compact_at the folded generators are materialised and
+    // the remaining rounds run as single-launch rounds over THEIR digit multiples (n0, Pall, cG, cH, table then describe the compacted set)
+    size_t compact_at;       // 0: this proof never compacts
+    bool compacted;
+    void* Daff;              // affine digit multiples m P_i (m = 1 .. 8) of the 2 n0 originals [G | H]: needs no challenge, queued at creation
+    hipEvent_t ev_side;      // ... on a sibling stream: recorded behind that work
+    bool side_pending;       // ev_side not yet waited for by the context's stream
     int device;
     // every buffer above is a block of the context's pool (recycled, no hipMalloc / hipFree per proof)
     DevPool* pool;
@@ -135,6 +143,113 @@ struct Ipp {
         return BP_OK;
     }
 
+
+    // ---- generator compaction (bp_compact.cuh) ----
+    // out[i] = affine form of in[i] for i < n, one field inversion for the whole array.  device_root: the inversion runs on one GPU lane
+    // (~0.4 ms of latency, no host round trip: for batches queued ahead of their use); otherwise the host inverts the root (~3 us + a sync).
+    // `hold` != nullptr: the batch runs on stream `s` (NOT the context's) with the root inverted on the device, and its scratch blocks
+    // stay with the state until it is freed (the pool recycles in the order of the context's stream only).
+    static int batch_to_affine(bp_ctx* ctx, const XyzzPacked<C>* in, size_t n, AffPacked<C>* out, hipStream_t s, bp_ipp_state* hold) {
+        if (n == 0) return BP_OK;
+        const size_t nb = (n + kBaiTile - 1) / kBaiTile;
+        if (nb > (size_t)kBlock * kBaiMidPer) return BP_ERR_ARG;
+        PoolBlock b_prod, b_inv;
+        void *p_prod = nullptr, *p_inv = nullptr;
+        if (hold) {
+            if (!hold->take(&p_prod, (nb + 1) * sizeof(FePacked<Fp>)) || !hold->take(&p_inv, nb * sizeof(FePacked<Fp>))) return BP_ERR_DEVICE;
+        } else {
+            if (!b_prod.alloc(ctx, (nb + 1) * sizeof(FePacked<Fp>)) || !b_inv.alloc(ctx, nb * sizeof(FePacked<Fp>))) return BP_ERR_DEVICE;
+            p_prod = b_prod.p; p_inv = b_inv.p;
+        }
+        auto* bprod = (FePacked<Fp>*)p_prod;
+        auto* binv = (FePacked<Fp>*)p_inv;
+        FePacked<Fp> zero;
+        memset(&zero, 0, sizeof zero);
+        hipLaunchKernelGGL(k_bai_block_products<C>, dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, bprod);
+        if (hold) {
+            hipLaunchKernelGGL((k_bai_middle<C, 2>), dim3(1), dim3(kBlock), 0, s, (const FePacked<Fp>*)bprod, (uint32_t)nb, zero, bprod + nb, binv);
+        } else {
+            hipLaunchKernelGGL((k_bai_middle<C, 0>), dim3(1), dim3(kBlock), 0, s, (const FePacked<Fp>*)bprod, (uint32_t)nb, zero, bprod + nb, binv);
+            HIPCHK(hipGetLastError());
+            int rc = host_pinned_reserve(ctx, sizeof(FePacked<Fp>));
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(ctx->host_pinned, bprod + nb, sizeof(FePacked<Fp>), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            FePacked<Fp> root;
+            memcpy(&root, ctx->host_pinned, sizeof root);
+            const FePacked<Fp> rinv = fe_pack(fr_inv_fast<Fp>(fe_unpack_words<Fp>(root.w)));      // (a value < 2p: the conversion out of Montgomery form reduces it)
+            hipLaunchKernelGGL((k_bai_middle<C, 1>), dim3(1), dim3(kBlock), 0, s, (const FePacked<Fp>*)bprod, (uint32_t)nb, rinv, bprod + nb, binv);
+        }
+        hipLaunchKernelGGL(k_bai_finish<C>, dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, (const FePacked<Fp>*)binv, out);
+        HIPCHK(hipGetLastError());
+        return BP_OK;
+    }
+
+    // Daff[(m - 1) * npts + i] = m P_i (affine), m = 1 .. 8, over the npts = 2 n0 originals [G | H] of the state.  Needs no challenge:
+    // queued at state creation on a SIBLING stream (bp_internal_helper), where it fills the gaps of the latency-bound first rounds;
+    // compact() makes the context's stream wait for ev_side.
+    static int build_original_multiples(bp_ipp_state* st) {
+        bp_ctx* ctx = st->ctx;
+        const size_t npts = 2 * st->n0, rows = (size_t)1 << (kSmallDigitBits - 1);
+        if (npts >= ((size_t)1 << 31)) return BP_ERR_ARG;
+        bp_ctx* side = bp_internal_helper(ctx, 0);
+        if (!side) return BP_ERR_DEVICE;
+        void* tmp = nullptr;
+        if (!st->take(&tmp, rows * npts * sizeof(XyzzPacked<C>)) || !st->take(&st->Daff, rows * npts * kPt)) return BP_ERR_DEVICE;
+        int rc = bp_internal_fork(ctx, side);
+        if (rc) return rc;
+        if (!st->ev_side) HIPCHK(hipEventCreateWithFlags(&st->ev_side, hipEventDisableTiming));
+        hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((npts + 63) / 64)), dim3(64), 0, side->stream, (const AffPacked<C>*)st->Pall, (uint32_t)npts,
+                           (XyzzPacked<C>*)tmp);
+        HIPCHK(hipGetLastError());
+        rc = batch_to_affine(ctx, (const XyzzPacked<C>*)tmp, rows * npts, (AffPacked<C>*)st->Daff, side->stream, st);
+        HIPCHK(hipEventRecord(st->ev_side, side->stream));
+        st->side_pending = true;
+        return rc;
+    }
+
+    // The folded generators of the current round, materialised (called by fold() when the live length reaches compact_at):
+    // afterwards n0 = the live length, Pall = [G' | H' | Q] (affine), c_G = c_H = 1 and table = the affine digit multiples of Pall.
+    static int compact(bp_ipp_state* st) {
+        bp_ctx* ctx = st->ctx;
+        hipStream_t s = ctx->stream;
+        const size_t n0 = st->n0, nj = st->n, nout = 2 * nj, m = nout + 1, rows = (size_t)1 << (kSmallDigitBits - 1);
+        int rc;
+        if (!st->Daff && (rc = build_original_multiples(st))) return rc;
+        if (st->side_pending) { HIPCHK(hipStreamWaitEvent(s, st->ev_side, 0)); st->side_pending = false; }
+        const int nwin = (C::Fr::BITS + 1 + kSmallDigitBits - 1) / kSmallDigitBits;      // 64 windows of 4 bits
+        ScalarWords bias;
+        for (int k = 0; k < 8; k++) bias.w[k] = 0x77777777u;                             // digit = nibble - 7
+        PoolBlock b_wsum, b_S, b_mx;
+        if (!b_wsum.alloc(ctx, (size_t)nwin * nout * sizeof(XyzzPacked<C>)) || !b_S.alloc(ctx, m * sizeof(XyzzPacked<C>)) ||
+            !b_mx.alloc(ctx, rows * m * sizeof(XyzzPacked<C>)))
+            return BP_ERR_DEVICE;
+        hipLaunchKernelGGL(k_compact_window_sums<C>, dim3((unsigned)((nout + kBlock - 1) / kBlock), (unsigned)nwin), dim3(kBlock), 0, s, (const AffPacked<C>*)st->Daff,
+                           2 * n0, 2 * n0, (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, (uint32_t)n0, (uint32_t)nj, 0, nwin, bias, (uint32_t)nout,
+                           (XyzzPacked<C>*)b_wsum.p);
+        BP_TRACE_SYNC(ctx, "k_compact_window_sums");
+        hipLaunchKernelGGL(k_compact_horner<C>, dim3((unsigned)((nout + kHornerQuads - 1) / kHornerQuads)), dim3(4 * kHornerQuads), 0, s,
+                           (const XyzzPacked<C>*)b_wsum.p, (uint32_t)nout, (uint32_t)nout, nwin, (const AffPacked<C>*)st->Q, (XyzzPacked<C>*)b_S.p);
+        BP_TRACE_SYNC(ctx, "k_compact_horner");
+        hipLaunchKernelGGL(k_digit_table_build_xyzz<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const XyzzPacked<C>*)b_S.p, (uint32_t)m, (XyzzPacked<C>*)b_mx.p);
+        HIPCHK(hipGetLastError());
+        bp_g1table* t = new (std::nothrow) bp_g1table();
+        if (!t) return BP_ERR_DEVICE;
+        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = kSmallDigitBits; t->W = (int)rows; t->digits = true; t->affine = true;
+        t->d = ctx->pool->get(rows * m * kPt, &t->cap);
+        if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+        if ((rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rows * m, (AffPacked<C>*)t->d, s, nullptr))) { bp_internal_table_free(t); return rc; }
+        BP_TRACE_SYNC(ctx, "compaction: digit multiples");
+        hipLaunchKernelGGL(k_fr_fill_one, dim3(blocks_for(nj)), dim3(kBlock), 0, s, (ScalarWords*)st->cG, (ScalarWords*)st->cH, nj);
+        HIPCHK(hipGetLastError());
+        if (st->table) bp_internal_table_free(st->table);
+        st->table = t;
+        st->Pall = t->d;                 // the first m rows (multiple 1) are [G' | H' | Q] themselves, affine
+        st->n0 = nj;
+        st->compacted = true;
+        return BP_OK;
+    }
+
     static int round(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
         bp_ctx* ctx = st->ctx;
         size_t h = st->n / 2;
@@ -180,6 +295,7 @@ struct Ipp {
             BP_TRACE_SYNC(ctx, "ipp fold scalars");
             st->n = h;
             st->first = false;
+            if (st->compact_at && !st->compacted && st->n == st->compact_at) return compact(st);
             return BP_OK;
         }
         BP_TRACE_SYNC(ctx, "ipp fold: launching");
@@ -951,6 +1067,8 @@ int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le,
 // ---- IPP device-resident state ------------------------------------------------------------------------------
 int bp_ipp_state_free(bp_ipp_state* st) {
     if (!st) return BP_OK;
+    if (st->side_pending) (void)hipEventSynchronize(st->ev_side);      // blocks in use on the sibling stream must not return to the pool yet
+    if (st->ev_side) (void)hipEventDestroy(st->ev_side);
     if (st->table) bp_internal_table_free(st->table);
     if (st->blocks) {
         for (auto& b : *st->blocks) st->pool->put(b.first, b.second);
@@ -1019,6 +1137,15 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { bp_ipp_state_free(st); return BP_ERR_DEVICE; }
     const bool digits = !st->fold_generators && n >= 16 && 2 * n + 1 <= kSmallDigitMax && st->ctx->tuning.small_msm && st->ctx->c_override <= 0;
+    {   // generator compaction: automatic for proofs of >= 8192 generators (at a live length of 4096); BP_TUNE_COMPACT_AT moves or disables it
+        const size_t knob = ctx->tuning.compact_at;
+        const size_t at = knob == 0 ? (n >= 8192 ? 4096 : 0) : knob == 1 ? 0 : knob;
+        st->compact_at = !st->fold_generators && ctx->tuning.small_msm && ctx->c_override <= 0 && at >= 16 && n > at && 2 * at + 1 <= kSmallDigitMax ? at : 0;
+    }
+    if (st->compact_at) {
+        rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::build_original_multiples(st) : Ipp<Bn254>::build_original_multiples(st);
+        if (rc) { bp_ipp_state_free(st); return rc; }
+    }
     if (!st->fold_generators && !digits && 2 * n + 1 > kSmallMsmMax) {     // smaller rounds run as ONE launch (k_small_msm): nothing for a table to merge
         rc = bp_internal_table_concat(ctx, G, 0, H, 0, n, Q_le, &st->table);
         if (rc) { bp_ipp_state_free(st); return rc; }

@@ -1,0 +1,311 @@
+// bp_compact.cuh -- gfx950 kernels that MATERIALISE folded generators in the middle of an inner-product proof.
+//
+// The default prover never folds G and H (bp_ipp.cuh: every round is a paired MSM over the original [G | H | Q] with per-generator
+// coefficients c_G, c_H), which replaced the reference's per-round G1::binary_scalar_mul fold (/root/reference src/ipp.rs:119,125,
+// 185,187 inside the loop :138-194) -- but it keeps paying a FULL-size MSM in every round, whatever the live length.  Once the live
+// length nj is small enough for the single-launch rounds (2 nj + 1 <= kSmallDigitMax terms) the folded generators
+//     G'_j = sum_{t < T} c_G[j + t nj] G[j + t nj],    H'_j likewise,    T = n0 / nj            (exactly the reference's G, H at that round)
+// are computed ONCE -- 2 nj independent T-term MSMs with full-size scalars -- and the remaining rounds run over [G' | H' | Q]:
+//   k_digit_table_build (bp_kernels.cuh)   D[m][i] = m P_i, m = 1 .. 8, for all 2 n0 originals         (needs no challenge: queued early)
+//   k_bai_*                                batch conversion of D to AFFINE rows (Montgomery's trick over the whole array)
+//   k_compact_window_sums                  W[w][o] = sum_t digit_w(c_t) P_t: lane per (output o, 4-bit window w), T mixed additions
+//   k_compact_horner                       S_o = sum_w 16^w W[w][o]: a strictly serial chain of 4 doublings + 1 addition per window,
+//                                          every operation on the four lanes of a quad (xyzz_lazy_dbl_quad / _add_quad)
+//   k_digit_table_build_xyzz, k_bai_*      digit multiples of the S_o (affine) for k_small_msm
+// With a window-multiples table the caller precomputed (rows 2^(64 k) P_i) the Horner chain is 60 doublings instead of 252: a scalar
+// is then K = 4 sub-scalars of 64 bits over K table rows and nwin = 16.
+#pragma once
+#include "bp_kernels.cuh"
+
+namespace bp {
+
+// ---------------------------------------------------------------------------------------------- batch XYZZ -> affine
+// out[i] = affine form of in[i] (canonical Montgomery rows; the identity -> all-zero row) with ONE field inversion for the whole
+// array: z_i = ZZ_i ZZZ_i (1 for the identity), product trees over lanes / blocks, the root inverted once (on the host: ~3 us of
+// binary Euclid, bp_host_tail.hpp -- or by one lane when nobody waits for the result), inverses handed back down the same trees,
+//     1 / ZZ = ZZZ / z,   1 / ZZZ = ZZ / z.
+// Layout: block b owns elements [b * kBaiTile, (b + 1) * kBaiTile), lane l the elements b * kBaiTile + e * kBlock + l.
+constexpr int kBaiPer = 4;
+constexpr int kBaiTile = kBaiPer * kBlock;
+constexpr int kBaiMidPer = 16;                       // block products per lane of the single middle block: n <= 256 * 16 * 1024 elements
+
+template <class P> struct FeLds { uint32_t v[P::NL]; };
+template <class P> __device__ __forceinline__ FeB<P, 2> lds_get(const FeLds<P>& s) { FeB<P, 2> r; for (int i = 0; i < P::NL; i++) r.v[i] = s.v[i]; return r; }
+template <class P> __device__ __forceinline__ void lds_put(FeLds<P>& s, const FeB<P, 2>& a) { for (int i = 0; i < P::NL; i++) s.v[i] = a.v[i]; }
+template <class P> __device__ __forceinline__ FeB<P, 2> feb_one2() { FeB<P, 2> r; for (int i = 0; i < P::NL; i++) r.v[i] = P::C.one[i]; return r; }
+template <class P> __device__ __forceinline__ FeB<P, 2> feb_load2(const FePacked<P>& p) {
+    const Fe<P> t = fe_unpack_words<P>(p.w);
+    FeB<P, 2> r;
+    for (int i = 0; i < P::NL; i++) r.v[i] = t.v[i];
+    return r;
+}
+template <class P> __device__ __forceinline__ FePacked<P> feb_store2(const FeB<P, 2>& a) {
+    Fe<P> t;
+    for (int i = 0; i < P::NL; i++) t.v[i] = a.v[i];
+    return fe_pack(t);                               // < 2p < 2^(32 NW)
+}
+
+// heap-shaped product tree over the kBlock leaves node[kBlock + l]: node[i] = node[2i] node[2i + 1], root node[1]
+template <class P> __device__ __forceinline__ void bai_tree_up(FeLds<P>* node) {
+#pragma unroll 1
+    for (int s = kBlock / 2; s >= 1; s >>= 1) {
+        __syncthreads();
+        if ((int)threadIdx.x < s) {
+            const int i = s + (int)threadIdx.x;
+            lds_put<P>(node[i], feb_mul(lds_get<P>(node[2 * i]), lds_get<P>(node[2 * i + 1])));
+        }
+    }
+    __syncthreads();
+}
+// node[1] holds the inverse of the root product: afterwards leaf node[kBlock + l] holds the inverse of leaf l's value
+template <class P> __device__ __forceinline__ void bai_tree_down(FeLds<P>* node) {
+#pragma unroll 1
+    for (int s = 1; s < kBlock; s <<= 1) {
+        __syncthreads();
+        if ((int)threadIdx.x < s) {
+            const int i = s + (int)threadIdx.x;
+            const FeB<P, 2> iv = lds_get<P>(node[i]), a = lds_get<P>(node[2 * i]), b = lds_get<P>(node[2 * i + 1]);
+            lds_put<P>(node[2 * i], feb_mul(iv, b));
+            lds_put<P>(node[2 * i + 1], feb_mul(iv, a));
+        }
+    }
+    __syncthreads();
+}
+
+// z of element i (ZZ * ZZZ in the lazy domain, < 2p), 1 for the identity / past the end
+template <class C> __device__ __forceinline__ FeB<typename C::Fp, 2> bai_z(const XyzzPacked<C>* in, size_t i, size_t n) {
+    using Fp = typename C::Fp;
+    if (i >= n) return feb_one2<Fp>();
+    const FeB<Fp, 2> zz = feb_load2<Fp>(in[i].zz);
+    uint32_t any = 0;
+    for (int k = 0; k < Fp::NL; k++) any |= zz.v[k];
+    if (!any) return feb_one2<Fp>();
+    return feb_mul(zz, feb_load2<Fp>(in[i].zzz));
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_bai_block_products(const XyzzPacked<C>* __restrict__ in, size_t n, FePacked<typename C::Fp>* __restrict__ bprod) {
+    using Fp = typename C::Fp;
+    __shared__ FeLds<Fp> node[2 * kBlock];
+    const size_t base = (size_t)blockIdx.x * kBaiTile + threadIdx.x;
+    FeB<Fp, 2> prod = bai_z<C>(in, base, n);
+#pragma unroll 1
+    for (int e = 1; e < kBaiPer; e++) prod = feb_mul(prod, bai_z<C>(in, base + (size_t)e * kBlock, n));
+    lds_put<Fp>(node[kBlock + threadIdx.x], prod);
+    bai_tree_up<Fp>(node);
+    if (threadIdx.x == 0) bprod[blockIdx.x] = feb_store2<Fp>(lds_get<Fp>(node[1]));
+}
+
+// Single block.  MODE 0: root[0] = product of the nb block products (the host inverts it).  MODE 1: binv[b] = 1 / bprod[b] given
+// root_inv = 1 / (their product).  MODE 2: both at once, the root inverted by lane 0 (a^(p-2): ~0.4 ms of one lane's time for the
+// 381-bit field -- for batches nobody is waiting for).
+template <class C, int MODE>
+__global__ void __launch_bounds__(kBlock) k_bai_middle(const FePacked<typename C::Fp>* __restrict__ bprod, uint32_t nb, FePacked<typename C::Fp> root_inv,
+                                                       FePacked<typename C::Fp>* __restrict__ root, FePacked<typename C::Fp>* __restrict__ binv) {
+    using Fp = typename C::Fp;
+    __shared__ FeLds<Fp> node[2 * kBlock];
+    FeB<Fp, 2> prod = feb_one2<Fp>();
+#pragma unroll 1
+    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) prod = feb_mul(prod, feb_load2<Fp>(bprod[b]));
+    lds_put<Fp>(node[kBlock + threadIdx.x], prod);
+    bai_tree_up<Fp>(node);
+    if (MODE == 0) {
+        if (threadIdx.x == 0) root[0] = feb_store2<Fp>(lds_get<Fp>(node[1]));
+        return;
+    }
+    if (threadIdx.x == 0) {
+        FeB<Fp, 2> ri;
+        if (MODE == 2) ri = feb_widen<2>(feb_from_strict<Fp>(fe_inv<Fp>(feb_to_strict(lds_get<Fp>(node[1])))));
+        else ri = feb_load2<Fp>(root_inv);
+        lds_put<Fp>(node[1], ri);
+    }
+    bai_tree_down<Fp>(node);
+    // the lane's inverse covers the product of ITS block products b = l, l + 256, ...: walk them from the last to the first
+    FeB<Fp, 2> run = lds_get<Fp>(node[kBlock + threadIdx.x]);
+    uint32_t cnt = 0;
+    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) cnt++;
+#pragma unroll 1
+    for (uint32_t k = cnt; k-- > 0;) {
+        FeB<Fp, 2> pre = feb_one2<Fp>();                       // product of the lane's values before the k-th (recomputed: cnt <= kBaiMidPer)
+#pragma unroll 1
+        for (uint32_t k2 = 0; k2 < k; k2++) pre = feb_mul(pre, feb_load2<Fp>(bprod[threadIdx.x + k2 * kBlock]));
+        const uint32_t b = threadIdx.x + k * kBlock;
+        binv[b] = feb_store2<Fp>(feb_mul(run, pre));
+        run = feb_mul(run, feb_load2<Fp>(bprod[b]));
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_bai_finish(const XyzzPacked<C>* __restrict__ in, size_t n, const FePacked<typename C::Fp>* __restrict__ binv,
+                                                       AffPacked<C>* __restrict__ out) {
+    using Fp = typename C::Fp;
+    __shared__ FeLds<Fp> node[2 * kBlock];
+    const size_t base = (size_t)blockIdx.x * kBaiTile + threadIdx.x;
+    FeB<Fp, 2> z[kBaiPer], pre[kBaiPer];                         // pre[e] = z[0] .. z[e]
+#pragma unroll
+    for (int e = 0; e < kBaiPer; e++) {
+        z[e] = bai_z<C>(in, base + (size_t)e * kBlock, n);
+        pre[e] = e == 0 ? z[0] : feb_mul(pre[e - 1], z[e]);
+    }
+    lds_put<Fp>(node[kBlock + threadIdx.x], pre[kBaiPer - 1]);
+    bai_tree_up<Fp>(node);
+    if (threadIdx.x == 0) lds_put<Fp>(node[1], feb_load2<Fp>(binv[blockIdx.x]));
+    bai_tree_down<Fp>(node);
+    FeB<Fp, 2> run = lds_get<Fp>(node[kBlock + threadIdx.x]);    // 1 / (z[0] .. z[3])
+#pragma unroll
+    for (int e = kBaiPer - 1; e >= 0; e--) {
+        const FeB<Fp, 2> zi = e == 0 ? run : feb_mul(run, pre[e - 1]);      // 1 / z[e]
+        if (e) run = feb_mul(run, z[e]);
+        const size_t i = base + (size_t)e * kBlock;
+        if (i >= n) continue;
+        const XyzzLazy<C> p = xyzz_lazy_unpack(in[i]);
+        Aff<C> a;
+        if (p.inf) { a.x = fe_zero<Fp>(); a.y = fe_zero<Fp>(); }
+        else {
+            a.x = feb_to_strict(feb_mul(p.x, feb_mul(zi, p.zzz)));          // X / ZZ
+            a.y = feb_to_strict(feb_mul(p.y, feb_mul(zi, p.zz)));           // Y / ZZZ
+        }
+        out[i] = aff_pack(a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- digit multiples of XYZZ points
+// mult[(m - 1) * n + t] = m S_t, m = 1 .. 8, from packed lazy points (the compacted generators): seven dependent full additions per lane
+// through ONE addition site (it handles the empty accumulator and S + S).
+template <class C>
+__global__ void __launch_bounds__(64) k_digit_table_build_xyzz(const XyzzPacked<C>* __restrict__ S, uint32_t n, XyzzPacked<C>* __restrict__ mult) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const XyzzLazy<C> p = xyzz_lazy_unpack(S[t]);
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+#pragma unroll 1
+    for (uint32_t m = 1; m <= (1u << (kSmallDigitBits - 1)); m++) {
+        acc = xyzz_lazy_add(acc, p);
+        mult[(size_t)(m - 1) * n + t] = xyzz_lazy_pack(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- window sums of the compaction
+// Lane (o, w): output o < 2 nj (o < nj: G'_o over c_G, else H'_(o - nj) over c_H), 4-bit window w < nwin of every sub-scalar:
+//     W[w][o] = sum_{t < T} sum_{k < K} digit_(nwin k + w)(c[j + t nj]) * Row_k(P_(j + t nj))
+// with the signed digits of c + bias (bias = 0x77..7: digit = nibble - 7 in [-7, 8], as the pipeline recodes), Row_k(P_i) = 2^(4 nwin k) P_i
+// and the digit's multiple LOADED from D: D[(|d| - 1) * drows + k * npts + i], affine rows (npts = 2 n0 points: G then H).
+// K = 1, nwin = 64: plain.  K = 4, nwin = 16: over the rows 2^(64 k) P_i of a precomputed table.
+// The loop is k_accumulate's single-path addition; the general one only for the rare doubling / cancellation.
+template <class C>
+__global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums(const AffPacked<C>* __restrict__ D, size_t drows, size_t npts, const ScalarWords* __restrict__ cG,
+                                                                   const ScalarWords* __restrict__ cH, uint32_t n0, uint32_t nj, int lgK, int nwin, ScalarWords bias,
+                                                                   uint32_t pitch, XyzzPacked<C>* __restrict__ wsum) {
+    using Fp = typename C::Fp;
+    const uint32_t o = blockIdx.x * kBlock + threadIdx.x, w = blockIdx.y;
+    if (o >= 2 * nj) return;
+    const uint32_t vec = o >= nj ? 1u : 0u, j = o - vec * nj;
+    const ScalarWords* sc = vec ? cH : cG;
+    const size_t pbase = (size_t)vec * n0 + j;
+    const uint32_t K = 1u << lgK, terms = (n0 / nj) << lgK;
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+    uint32_t e = 0;
+    // term e: t = e >> lgK, k = e & (K - 1)
+    auto fetch = [&](uint32_t ee, Aff<C>& p, bool& neg) -> bool {
+        const uint32_t t = ee >> lgK, k = ee & (K - 1);
+        uint64_t q[4];
+        add256(q, sc[j + (size_t)t * nj], bias);
+        const int d = (int)window_bits(q, 4 * (int)(nwin * k + w), 4) - 7;
+        if (d == 0) return false;
+        const uint32_t m = (uint32_t)(d < 0 ? -d : d);
+        p = aff_unpack(D[(size_t)(m - 1) * drows + (size_t)k * npts + pbase + (size_t)t * nj]);
+        neg = d < 0;
+        return !aff_is_inf(p);
+    };
+    // The accumulator starts as the first term with a non-zero digit, found by a scan of DIGITS only: were that term taken inside the
+    // addition loop (k_accumulate's shape), the lanes whose first digit is zero -- one in sixteen -- would sit out the whole inner loop of
+    // their wave and then run theirs alone: twice the time (measured: 2.49 ms for 8.4 M additions).
+    auto restart = [&]() {
+        Aff<C> p; bool neg;
+        while (e < terms && !fetch(e, p, neg)) e++;
+        if (e < terms) {
+            if (neg) p.y = fe_neg(p.y);
+            acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
+            e++;
+        }
+    };
+    restart();
+    while (e < terms) {
+        while (e < terms) {
+            Aff<C> p; bool neg;
+            if (!fetch(e, p, neg)) { e++; continue; }
+            FeB<Fp, 2> qy = feb_widen<2>(feb_from_strict<Fp>(p.y));
+            if (neg) qy = feb_neg_canonical<Fp>(p.y);
+            if (!xyzz_lazy_add_aff_fast(acc, feb_from_strict<Fp>(p.x), qy)) break;     // same x: doubling or cancellation, below
+            e++;
+        }
+        if (e < terms) {
+            Aff<C> p; bool neg;
+            if (fetch(e, p, neg)) {
+                if (neg) p.y = fe_neg(p.y);
+                xyzz_lazy_add_aff(acc, p);
+            }
+            e++;
+            if (acc.inf) restart();
+        }
+    }
+    wsum[(size_t)w * pitch + o] = xyzz_lazy_pack(acc);
+}
+
+// ---------------------------------------------------------------------------------------------- Horner over the window sums
+// S_o = sum_w 16^w W[w][o]: per output a strictly serial chain of (nwin - 1) x (4 doublings + 1 addition); a quad of lanes per output,
+// every operation shared by its four lanes through two LDS slots (accumulator, incoming window sum).  Blocks of one wave (16
+// outputs) so that the ~2 nj / 16 waves spread over all CUs.  extra (optional): one more affine point appended as S_nout (the Q of
+// the inner-product argument), so that the digit multiples of [G' | H' | Q] come out of one array.
+constexpr int kHornerQuads = 16;
+template <class C>
+__global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzPacked<C>* __restrict__ wsum, uint32_t nout, uint32_t pitch, int nwin,
+                                                                     const AffPacked<C>* __restrict__ extra, XyzzPacked<C>* __restrict__ out) {
+    using Fp = typename C::Fp;
+    constexpr int NW = Fp::NW;
+    __shared__ XyzzPacked<C> lds[2 * kHornerQuads];
+    const int quad = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3;
+    const uint32_t o = blockIdx.x * kHornerQuads + quad;
+    const uint32_t oo = o < nout ? o : nout - 1;                 // a quad past the end shadows the last output (uniform trip counts), stores nothing
+    uint32_t* A = (uint32_t*)&lds[2 * quad];
+    uint32_t* B = (uint32_t*)&lds[2 * quad + 1];
+    {   // lane q moves field q
+        const uint32_t* src = (const uint32_t*)&wsum[(size_t)(nwin - 1) * pitch + oo];
+        for (int i = 0; i < NW; i++) A[q * NW + i] = src[q * NW + i];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int w = nwin - 2; w >= 0; w--) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            xyzz_lazy_dbl_quad<C>(lds, 2 * quad, q);
+            __syncthreads();
+        }
+        const uint32_t* src = (const uint32_t*)&wsum[(size_t)w * pitch + oo];
+        for (int i = 0; i < NW; i++) B[q * NW + i] = src[q * NW + i];
+        __syncthreads();
+        xyzz_lazy_add_quad<C>(lds, 2 * quad, 2 * quad + 1, q);
+        __syncthreads();
+    }
+    if (o < nout) {
+        uint32_t* dst = (uint32_t*)&out[o];
+        for (int i = 0; i < NW; i++) dst[q * NW + i] = A[q * NW + i];
+    }
+    if (extra && blockIdx.x == 0 && threadIdx.x == 0) {
+        const Aff<C> p = aff_unpack(*extra);
+        out[nout] = xyzz_lazy_pack(xyzz_lazy_from_strict(xyzz_from_aff(p)));
+    }
+}
+
+// v[i] = 1 (canonical) for i < n: the coefficient vectors of a freshly compacted generator set
+static __global__ void __launch_bounds__(kBlock) k_fr_fill_one(ScalarWords* __restrict__ a, ScalarWords* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ScalarWords one;
+    one.w[0] = 1;
+    for (int k = 1; k < 8; k++) one.w[k] = 0;
+    a[i] = one;
+    b[i] = one;
+}
+
+}  // namespace bp

@@ -549,6 +549,70 @@ __device__ __forceinline__ void xyzz_lazy_add_quad(XyzzPacked<C>* slots, int ia,
         fe_pack_words<Fp>(wa + 2 * NW, t);
     }
 }
+
+// One DOUBLING on four lanes (round 4; the Horner chains of the generator compaction, bp_compact.cuh): slots[ia] = 2 slots[ia].
+// dbl-2008-s-1 with W = U V never formed (W Y = (U Y) V, W ZZZ = (U ZZZ) V), so that the ten products have depth THREE:
+//     round 1   V = U^2            X2 = X^2          A = U ZZZ         B = U Y                 (U = 2Y)
+//     round 2   S = X V            MM = M^2          ZZZ3 = A V        BV = B V                (M = 3 X2)
+//     round 3   T1 = M (S - X3)    --                ZZ3 = V ZZ        --                      (X3 = MM - 2S, Y3 = T1 - BV)
+// Bounds as in xyzz_lazy_dbl: U < 8p (Y < 4p), M < 6p, X3 < 6p, S - X3 + 8p < 10p; every product <= 8 * 8; results X3 < 8p, Y3 < 4p,
+// ZZ3, ZZZ3 < 2p.  ~1 450 wave instructions against ~3 400 for the one-lane doubling.  The identity stays the identity; y = 0
+// cannot occur (odd group order).  All four lanes of the quad must be active.
+template <class C>
+__device__ __forceinline__ void xyzz_lazy_dbl_quad(XyzzPacked<C>* slots, int ia, int q) {
+    using Fp = typename C::Fp;
+    constexpr int NW = Fp::NW;
+    uint32_t* wa = (uint32_t*)&slots[ia];
+    uint32_t m0 = q == 0 ? ~0u : 0u, m1 = q == 1 ? ~0u : 0u;
+    asm volatile("" : "+v"(m0), "+v"(m1));
+    const int f1 = q == 1 ? 0 : 1;                                     // first operand:   Y   X   Y     Y
+    const int f2 = q == 0 ? 0 : q == 2 ? 3 : f1;                       // second operand:  X   X   ZZZ   Y
+    FeB<Fp, 8> L1, L2, U;
+    FeB<Fp, 2> ZZ;
+    { Fe<Fp> t = fe_unpack_words<Fp>(wa + f1 * NW); for (int i = 0; i < Fp::NL; i++) L1.v[i] = t.v[i]; }
+    { Fe<Fp> t = fe_unpack_words<Fp>(wa + f2 * NW); for (int i = 0; i < Fp::NL; i++) L2.v[i] = t.v[i]; }
+    { Fe<Fp> t = fe_unpack_words<Fp>(wa + 2 * NW); for (int i = 0; i < Fp::NL; i++) ZZ.v[i] = t.v[i]; }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < Fp::NL; i++) nz |= ZZ.v[i];
+    if (nz == 0) return;                                               // 2 * identity (every lane of the quad read the same ZZ)
+    {   // U = 2Y on the lanes that loaded Y (< 4p, so U < 8p); lane 1 doubles its X here and never uses the result
+        const FeB<Fp, 16> d = feb_add(L1, L1);
+        for (int i = 0; i < Fp::NL; i++) U.v[i] = d.v[i];
+    }
+    // ---- round 1
+    const FeB<Fp, 8> a1 = feb_select<8>(m1, L1, U), b1 = feb_select<8>(m0, U, L2);
+    const FeB<Fp, 2> r1 = feb_mul(a1, b1);                             // V | X2 | A | B
+    const FeB<Fp, 2> V = feb_quad_perm<kQuadBcast0>(r1);
+    const FeB<Fp, 6> M3 = feb_add(feb_add(r1, r1), r1);                // lane 1: M = 3 X^2
+    // ---- round 2
+    const FeB<Fp, 8> a2 = feb_select<8>(m0, L2, feb_select<6>(m1, M3, r1));
+    const FeB<Fp, 6> b2 = feb_select<6>(m1, M3, V);
+    const FeB<Fp, 2> r2 = feb_mul(a2, b2);                             // S | MM | ZZZ3 | BV
+    const FeB<Fp, 2> S = feb_quad_perm<kQuadBcast0>(r2), MM = feb_quad_perm<kQuadBcast1>(r2);
+    const FeB<Fp, 6> X3 = feb_sub<2>(feb_sub<2>(MM, S), S);
+    const FeB<Fp, 10> SX = feb_sub<8>(S, X3);
+    // ---- round 3
+    const FeB<Fp, 6> Mb = feb_quad_perm<kQuadBcast1>(M3);
+    const FeB<Fp, 6> a3 = feb_select<6>(m0, Mb, V);
+    const FeB<Fp, 10> b3 = feb_select<10>(m0, SX, ZZ);
+    const FeB<Fp, 2> r3 = feb_mul(a3, b3);                             // T1 | -- | ZZ3 | --        (6 * 10)
+    const FeB<Fp, 2> BV = feb_quad_perm<kQuadBcast3>(r2);
+    const FeB<Fp, 4> Y3 = feb_sub<2>(r3, BV);
+    // ---- the result: lane 0 X3 and Y3, lane 2 ZZ3 and ZZZ3
+    if (q == 0) {
+        XyzzLazy<C> t;                                                 // (packing X needs the conditional 4p of xyzz_lazy_pack)
+        t.x = feb_widen<8>(X3); t.y = Y3; t.zz = r3; t.zzz = r3; t.inf = false;
+        const XyzzPacked<C> pk = xyzz_lazy_pack(t);
+        for (int i = 0; i < NW; i++) { wa[i] = pk.x.w[i]; wa[NW + i] = pk.y.w[i]; }
+    } else if (q == 2) {
+        Fe<Fp> t;
+        for (int i = 0; i < Fp::NL; i++) t.v[i] = r3.v[i];
+        fe_pack_words<Fp>(wa + 2 * NW, t);
+        for (int i = 0; i < Fp::NL; i++) t.v[i] = r2.v[i];
+        fe_pack_words<Fp>(wa + 3 * NW, t);
+    }
+}
 #endif
 
 }  // namespace bp

@@ -117,8 +117,9 @@ struct F64 {
         sub_n(t, y);
         add_n(x, t);                                           // x + (p - y) < p
     }
-    // r = a^-1 (Montgomery in, Montgomery out), a != 0 mod p
+    // r = a^-1 (Montgomery in, Montgomery out); 0 -> 0 (as a^(p-2) gives; the Euclid loop below would never leave u = 0)
     void inverse(uint64_t* r, const uint64_t* a) const {
+        if (is_zero(a)) { memset(r, 0, sizeof(uint64_t) * N); return; }
         uint64_t u[N], v[N], x1[N] = {}, x2[N] = {};
         memcpy(u, a, sizeof u);
         memcpy(v, mod, sizeof v);
@@ -196,6 +197,7 @@ private:
         load(ZZ, r.zz.w);
         if (f.is_zero(ZZ)) { p.inf = true; return p; }
         load(X, r.x.w); load(Y, r.y.w); load(p.z, r.zzz.w);
+        if (f.is_zero(p.z)) { p.inf = true; return p; }          // ZZZ = 0 with ZZ != 0 is no point (a malformed record from another rank): identity, not Z = 0
         f.sqr(t, ZZ); f.mul(p.x, X, t);
         f.sqr(t, p.z); f.mul(p.y, Y, t);
         p.inf = false;

@@ -99,110 +99,7 @@ struct DevPool {
     void destroy() { trim(); delete this; }
 };
 
-// One helper thread per context for host work that can run beside the calling thread (the second serial tail of a paired
-// MSM): started on first use, parked on a condition variable in between (spawning a std::thread per pair cost ~40 us each).
-struct HostWorker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, done = true, quit = false, started = false;
-    bool submit(std::function<void()> f) {
-        std::unique_lock<std::mutex> lk(mu);
-        if (!started) {
-            try { th = std::thread([this] { run(); }); } catch (...) { return false; }
-            started = true;
-        }
-        job = std::move(f);
-        has_job = true;
-        done = false;
-        cv.notify_all();
-        return true;
-    }
-    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return done; }); }
-    void run() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [this] { return has_job || quit; });
-            if (quit) return;
-            std::function<void()> f = std::move(job);
-            has_job = false;
-            lk.unlock();
-            f();
-            lk.lock();
-            done = true;
-            cv.notify_all();
-        }
-    }
-    ~HostWorker() {
-        if (!started) return;
-        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
-        th.join();
-    }
-};
-
-// A few helper threads per context for the host tail's independent Horner chains (bp_host_tail.hpp): run(njobs, fn) executes
-// fn(0) .. fn(njobs - 1) on the helpers AND the calling thread and returns when all are done.  Threads start on first use and park
-// on a condition variable in between.  One run at a time per pool (a context is used by one host thread).
-struct HostPool {
-    std::vector<std::thread> th;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    const std::function<void(int)>* fn = nullptr;
-    std::atomic<int> njobs{0};
-    std::atomic<int> next{0};
-    int pending = 0;
-    uint64_t epoch = 0;
-    bool quit = false;
-    static constexpr int kMaxHelpers = 15;
-    void ensure(int helpers) {
-        if (helpers > kMaxHelpers) helpers = kMaxHelpers;
-        while ((int)th.size() < helpers) {
-            try { th.emplace_back([this] { worker(); }); } catch (...) { return; }     // fewer helpers: the caller's thread does the rest
-        }
-    }
-    void drain() {                                             // claim and run jobs until none is left
-        for (;;) {
-            const int j = next.fetch_add(1);
-            if (j >= njobs.load()) return;
-            (*fn)(j);
-            std::lock_guard<std::mutex> lk(mu);
-            if (--pending == 0) cv_done.notify_all();
-        }
-    }
-    void run(int n, const std::function<void(int)>& f, int helpers) {
-        if (n <= 0) return;
-        if (n == 1 || helpers <= 0) { for (int j = 0; j < n; j++) f(j); return; }
-        ensure(helpers < n - 1 ? helpers : n - 1);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            fn = &f; njobs.store(n); pending = n; epoch++;
-            next.store(0);                                     // last: a helper that claims a job sees fn / njobs of THIS run
-        }
-        cv_job.notify_all();
-        drain();
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [this] { return pending == 0; });
-        njobs.store(0);                                        // late wakers find nothing to claim
-    }
-    void worker() {
-        uint64_t seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_job.wait(lk, [&] { return quit || epoch != seen; });
-                if (quit) return;
-                seen = epoch;
-            }
-            drain();
-        }
-    }
-    ~HostPool() {
-        { std::lock_guard<std::mutex> lk(mu); quit = true; }
-        cv_job.notify_all();
-        for (auto& t : th) t.join();
-    }
-};
+#include "bp_hostpool.hpp"
 
 // Engineering knobs of the MSM pipeline (bp_ctx_set_tuning): 0 = automatic.  Every value is validated when it is set.
 struct bp_tuning {
@@ -210,6 +107,7 @@ struct bp_tuning {
     uint32_t reduce_m = 0;      // buckets per bucket-reduce thread: a power of two in [1, 16384]
     uint64_t task_target = 0;   // task count the accumulate aims at: [1024, 2^28]
     bool small_msm = true;      // single-launch path for n <= 512
+    uint32_t compact_at = 0;    // inner-product prover: live length at which the folded generators are materialised (0 automatic, 1 never)
 };
 
 struct bp_ctx {
@@ -315,6 +213,7 @@ struct bp_g1table {
     // = m P_i for m = 1 .. 2^(c-1), packed lazy XYZZ (W = 2^(c-1) rows).  Built by the inner-product state for its [G | H | Q] when a
     // round is <= kSmallMsmMax terms: the lanes then load their digit's multiple instead of computing it (library-internal).
     bool digits = false;
+    bool affine = false;     // digits only: the rows are canonical AFFINE points (AffPacked) instead of lazy XYZZ (bp_compact.cuh: batch conversion)
 };
 extern "C" void bp_internal_table_free(bp_g1table* t);
 int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out);

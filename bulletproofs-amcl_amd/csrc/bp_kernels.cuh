@@ -851,10 +851,14 @@ __global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>
     }
 }
 
-template <class C>
+// MODE (round 4: one body per way of obtaining a term -- with all three in one kernel the BN254 instantiation needed 512 VGPRs + 256
+// AGPRs and still spilled 153 registers): 0 = the lane multiplies its point by the digit (doubling chain); 1 = it loads
+// the digit's multiple from `mult` as a packed lazy XYZZ point, full addition; 2 = `mult` holds AFFINE rows (AffPacked, canonical:
+// the batch conversion of bp_compact.cuh), mixed addition -- 8M + 2S instead of 12M + 2S per term of the lane's serial chain.
+template <class C, int MODE>
 __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __restrict__ pts, const ScalarWords* __restrict__ sc1,
                                                       const ScalarWords* __restrict__ sc2, uint32_t n, WinTab tab,
-                                                      XyzzPacked<C>* __restrict__ window_sum, const XyzzPacked<C>* __restrict__ mult) {
+                                                      XyzzPacked<C>* __restrict__ window_sum, const void* __restrict__ mult) {
     __shared__ XyzzPacked<C> lds[kBlock];
     const int w = blockIdx.x, wps = tab.W / tab.nsets, set = w / wps;
     const int cw = tab.cw[w], off = tab.off[w];
@@ -866,21 +870,25 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
         int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
         if (d == 0) continue;
-        XyzzLazy<C> acc;
-        if (mult) {
-            acc = xyzz_lazy_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n + t]);
+        if (MODE == 2) {
+            Aff<C> p = aff_unpack(((const AffPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n + t]);
+            if (d < 0) p.y = fe_neg(p.y);
+            xyzz_lazy_add_aff(mine, p);
+        } else if (MODE == 1) {
+            XyzzLazy<C> acc = xyzz_lazy_unpack(((const XyzzPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n + t]);
             if (d < 0 && !acc.inf) acc.y = feb_neg<4>(acc.y);
+            mine = xyzz_lazy_add(mine, acc);
         } else {
             Aff<C> p = aff_unpack(pts[t]);
             if (d < 0) { p.y = fe_neg(p.y); d = -d; }
-            acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
+            XyzzLazy<C> acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
 #pragma unroll 1
             for (int i = 30 - __clz(d); i >= 0; i--) {            // bits below the leading one
                 acc = xyzz_lazy_dbl(acc);
                 if ((d >> i) & 1) xyzz_lazy_add_aff(acc, p);
             }
+            mine = xyzz_lazy_add(mine, acc);
         }
-        mine = xyzz_lazy_add(mine, acc);
     }
     mine = block_tree_sum_quad<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
     if (threadIdx.x == 0) window_sum[tab.roff[w] + blockIdx.y] = xyzz_lazy_pack(mine);

@@ -89,6 +89,11 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 1536 terms (and, inside an inner-product proof of 16 .. 4096
                                * generators, for its rounds of up to 8193 terms over precomputed digit multiples) */
 #define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
+#define BP_TUNE_COMPACT_AT 6  /* inner-product prover (bp_ipp_create, round API): live length at which the folded generators are materialised once
+                               * and the remaining rounds run as single launches over their digit multiples, instead of a full-size paired MSM in
+                               * every round (/root/reference src/ipp.rs:181-188 folds G, H every round; this is that fold, done once).  0 = automatic
+                               * (4096, for proofs of >= 8192 generators), 1 = never, else a power of two in [16, 4096]: every longer proof compacts
+                               * there.  Proof bytes do not depend on it. */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
 /* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
  * of a small proof; blocks are recycled in stream order).  bp_ctx_trim returns the cached blocks to the driver. */

@@ -235,6 +235,43 @@ def test_ipp_random_vs_oracle(bp, ctxs, name, n, unit_gf, prover_mode):
                         proof.L, proof.R, proof.lg_n) == 0
 
 
+@pytest.mark.parametrize("name,n,at,unit_gf", [("bls12_381", 64, 16, True), ("bls12_381", 256, 16, False), ("bn254", 128, 32, False), ("bn254", 512, 16, True),
+                                               ("bls12_381", 1024, 512, False), ("bn254", 64, 32, False)])
+def test_ipp_generator_compaction_vs_oracle(bp, ctxs, name, n, at, unit_gf):
+    """Generator compaction (bp_compact.cuh; /root/reference src/ipp.rs:181-188 done once instead of never): with BP_TUNE_COMPACT_AT the
+    prover materialises the folded generators when the live length reaches `at` (n / at = 2 .. 16 originals per output) and finishes over
+    their digit multiples.  Proof bytes = the oracle's = the bytes without compaction; the round API crosses the switch as well."""
+    ctx = ctxs[name]
+    cid = ctx.curve
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 41000 + n + at, unit_gf)
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes(), n)
+    assert rc == 0
+    try:
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, 1)            # never
+        plain = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, at)
+        proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        st = bp.IPPState(ctx, Gv, Hv, Q, Gf, Hf, a, b)    # the same through bp_ipp_round / bp_ipp_fold with the caller's transcript
+        tr = bp.Transcript(b"innerproduct")
+        tr.append_message(b"dom-sep", b"ipp v1")
+        tr.append_u64(b"n", n)
+        Ls, Rs = b"", b""
+        while len(st) > 1:
+            L, R = st.round()
+            tr.commit_point(cid, b"L", L); tr.commit_point(cid, b"R", R)
+            u = tr.challenge_scalar(cid, b"u")
+            st.fold(u, bp.fr_inverse(cid, u))
+            Ls += L; Rs += R
+        fa, fb = st.finish()
+    finally:
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, 0)
+    assert (plain.L, plain.R, plain.a, plain.b) == want
+    assert (proof.L, proof.R, proof.a, proof.b) == want
+    assert (Ls, Rs, fa, fb) == want
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+
+
 @pytest.mark.parametrize("name,n", [("bls12_381", 32), ("bn254", 64), ("bls12_381", 1024)])
 def test_ipp_degenerate_generators_vs_oracle(bp, ctxs, name, n):
     """Generators with structure the digit-multiples table and the four-lane tree must survive: identity points, a repeated point,

@@ -78,3 +78,16 @@ def test_verification_scalars_match_oracle_and_golden(bp, golden, name):
         assert rc == 0 and got == want, c["name"]
         with pytest.raises(bp.VerificationError):                     # n != 1 << lg_n  (src/ipp.rs:274-276)
             bp.IPP.verification_scalars(cid, L, R, 2 * n, bp.Transcript(b"innerproduct"))
+
+
+def test_hostpool_alternating_runs_under_tsan(tmp_path):
+    """ADVICE r3 (medium): HostPool::run must not let a helper carry a failed claim of one run into the next (larger) run.
+    tests/cpp/hostpool_stress.cpp alternates run(4) / run(8) with tiny jobs; built with ThreadSanitizer, every job runs exactly once."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "hostpool_stress")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", os.path.join(root, "tests", "cpp", "hostpool_stress.cpp"), "-o", exe])
+    p = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "hostpool_stress ok" in p.stdout, p.stdout + p.stderr
+    assert "ThreadSanitizer" not in p.stderr, p.stderr
