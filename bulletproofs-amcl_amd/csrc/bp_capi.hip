@@ -487,12 +487,15 @@ struct Impl {
     static int msm2(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, uint8_t* out1_le, uint8_t* out2_le, size_t nnz = 0, const bp_g1table* tb = nullptr) {
         if (n == 0) { memset(out1_le, 0, 2 * 4 * Fp::NW); memset(out2_le, 0, 2 * 4 * Fp::NW); return BP_OK; }
         MsmGeom g;
+        bp_prof().lap(0);
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts, (const ScalarWords*)sc1, n, g, (const ScalarWords*)sc2, nnz, tb);
         if (rc) return rc;
         const int R1 = g.nrec / 2;                      // records of one scalar set
         if ((rc = host_pinned_reserve(ctx, (size_t)g.nrec * kXyzzBytes))) return rc;
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)g.nrec * kXyzzBytes, hipMemcpyDeviceToHost, ctx->stream));
+        bp_prof().lap(1);
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        bp_prof().lap(2);
         collect_timing(ctx);
         // the two tails are independent: their Horner chains run side by side on the context's helper threads
         const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
@@ -500,6 +503,7 @@ struct Impl {
         const uint16_t* poss[2] = {g.rpos, g.rpos + R1};
         uint8_t* outs[2] = {out1_le, out2_le};
         fold_parallel(ctx, 2, recs, 1, R1, poss, outs);
+        bp_prof().lap(3);
         return BP_OK;
     }
 
@@ -1082,6 +1086,7 @@ static void recycle_block(DevPool* pool, int device, void* d, size_t cap, bool e
 int bp_g1vec_free(bp_g1vec* v) {
     if (!v) return BP_OK;
     if (v->table) bp_internal_table_free(v->table);
+    if (v->ctable) bp_internal_table_free(v->ctable);
     if (v->owned && v->d) recycle_block(v->pool, v->device, v->d, v->cap, v->exported);
     delete v;
     return BP_OK;
@@ -1097,13 +1102,25 @@ int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits) {
         while (((size_t)1 << (lg + 1)) <= v->n) lg++;
         c = lg - 1 < 8 ? 8 : lg - 1 > 16 ? 16 : lg - 1;
     }
+    if (ctx->device != v->device) return BP_ERR_ARG;            // the table lives in ctx's pool and is built on ctx's stream: same device as the vector
     if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
-    return bp_internal_table_build(ctx, v->d, v->n, c, &v->table);
+    if (v->ctable) { bp_internal_table_free(v->ctable); v->ctable = nullptr; }
+    rc = bp_internal_table_build(ctx, v->d, v->n, c, &v->table);
+    if (rc == BP_OK) rc = bp_internal_ctable_build(ctx, v->table, &v->ctable);
+    // A one-time cost: complete the build before returning, so that MSMs issued on OTHER contexts (shards, sibling streams) can
+    // never read rows that k_table_build has not written yet.
+    if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_DEVICE;
+    if (rc != BP_OK) {
+        if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
+        if (v->ctable) { bp_internal_table_free(v->ctable); v->ctable = nullptr; }
+    }
+    return rc;
 }
 
 int bp_g1vec_drop_table(bp_g1vec* v) {
     if (!v) return BP_ERR_ARG;
     if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
+    if (v->ctable) { bp_internal_table_free(v->ctable); v->ctable = nullptr; }
     return BP_OK;
 }
 
@@ -1112,7 +1129,8 @@ int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_
     const bp_g1table* t = v->table;
     if (window_bits) *window_bits = t ? t->c : 0;
     if (windows) *windows = t ? t->W : 0;
-    if (bytes) *bytes = t ? (size_t)t->W * t->n * 2 * (size_t)fp_bytes_of(v->ctx->curve) : 0;
+    if (bytes) *bytes = (t ? (size_t)t->W * t->n : 0) * 2 * (size_t)fp_bytes_of(v->ctx->curve) +
+                        (v->ctable ? (size_t)v->ctable->W * v->ctable->K * v->ctable->n * 2 * (size_t)fp_bytes_of(v->ctx->curve) : 0);   // + the compaction table
     return BP_OK;
 }
 

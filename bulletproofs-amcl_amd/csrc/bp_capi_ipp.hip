@@ -37,7 +37,9 @@ struct bp_ipp_state {
     // the remaining rounds run as single-launch rounds over THEIR digit multiples (n0, Pall, cG, cH, table then describe the compacted set)
     size_t compact_at;       // 0: this proof never compacts
     bool compacted;
-    void* Daff;              // affine digit multiples m P_i (m = 1 .. 8) of the 2 n0 originals [G | H]: needs no challenge, queued at creation
+    const bp_g1table *ctG, *ctH;   // compaction tables of G and H (bp_g1vec_precompute) when both have one: nothing to build, Horner chain of 60 doublings
+    size_t ctG_off, ctH_off;
+    void* Daff;              // otherwise: affine digit multiples m P_i (m = 1 .. 8) of the 2 n0 originals [G | H]: needs no challenge, queued at creation
     hipEvent_t ev_side;      // ... on a sibling stream: recorded behind that work
     bool side_pending;       // ev_side not yet waited for by the context's stream
     int device;
@@ -185,6 +187,20 @@ struct Ipp {
         return BP_OK;
     }
 
+    // the XYZZ digit multiples of a table (bp_internal_digit_table_build) -> affine rows, in place of the old block
+    static int digit_table_to_affine(bp_ctx* ctx, bp_g1table* t) {
+        if (!t || !t->digits || t->affine) return BP_OK;
+        const size_t rows = (size_t)t->W * t->n;
+        size_t cap = 0;
+        void* d = ctx->pool->get(rows * kPt, &cap);
+        if (!d) return BP_ERR_DEVICE;
+        int rc = batch_to_affine(ctx, (const XyzzPacked<C>*)t->d, rows, (AffPacked<C>*)d, ctx->stream, nullptr);
+        if (rc) { ctx->pool->put(d, cap); return rc; }
+        ctx->pool->put(t->d, t->cap);            // recycled in stream order: the conversion above is queued before any later user
+        t->d = d; t->cap = cap; t->affine = true;
+        return BP_OK;
+    }
+
     // Daff[(m - 1) * npts + i] = m P_i (affine), m = 1 .. 8, over the npts = 2 n0 originals [G | H] of the state.  Needs no challenge:
     // queued at state creation on a SIBLING stream (bp_internal_helper), where it fills the gaps of the latency-bound first rounds;
     // compact() makes the context's stream wait for ev_side.
@@ -215,20 +231,29 @@ struct Ipp {
         hipStream_t s = ctx->stream;
         const size_t n0 = st->n0, nj = st->n, nout = 2 * nj, m = nout + 1, rows = (size_t)1 << (kSmallDigitBits - 1);
         int rc;
-        if (!st->Daff && (rc = build_original_multiples(st))) return rc;
+        const bool tabled = st->ctG && st->ctH;
+        if (!tabled && !st->Daff && (rc = build_original_multiples(st))) return rc;
         if (st->side_pending) { HIPCHK(hipStreamWaitEvent(s, st->ev_side, 0)); st->side_pending = false; }
-        const int nwin = (C::Fr::BITS + 1 + kSmallDigitBits - 1) / kSmallDigitBits;      // 64 windows of 4 bits
+        const int lgK = tabled ? 2 : 0;                                                  // tables: a scalar is 4 sub-scalars of 64 bits over the rows 2^(64 k) P
+        const int nwin = ((C::Fr::BITS + 1 + kSmallDigitBits - 1) / kSmallDigitBits) >> lgK;      // 64 (16) windows of 4 bits
+        const AffPacked<C>*DG, *DH;
+        size_t drowsG, drowsH, ksG, ksH;
+        if (tabled) {
+            DG = (const AffPacked<C>*)st->ctG->d + st->ctG_off; drowsG = (size_t)st->ctG->K * st->ctG->n; ksG = st->ctG->n;
+            DH = (const AffPacked<C>*)st->ctH->d + st->ctH_off; drowsH = (size_t)st->ctH->K * st->ctH->n; ksH = st->ctH->n;
+        } else {
+            DG = (const AffPacked<C>*)st->Daff; DH = DG + n0; drowsG = drowsH = 2 * n0; ksG = ksH = 0;
+        }
         ScalarWords bias;
         for (int k = 0; k < 8; k++) bias.w[k] = 0x77777777u;                             // digit = nibble - 7
         PoolBlock b_wsum, b_S, b_mx;
         if (!b_wsum.alloc(ctx, (size_t)nwin * nout * sizeof(XyzzPacked<C>)) || !b_S.alloc(ctx, m * sizeof(XyzzPacked<C>)) ||
             !b_mx.alloc(ctx, rows * m * sizeof(XyzzPacked<C>)))
             return BP_ERR_DEVICE;
-        hipLaunchKernelGGL(k_compact_window_sums<C>, dim3((unsigned)((nout + kBlock - 1) / kBlock), (unsigned)nwin), dim3(kBlock), 0, s, (const AffPacked<C>*)st->Daff,
-                           2 * n0, 2 * n0, (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, (uint32_t)n0, (uint32_t)nj, 0, nwin, bias, (uint32_t)nout,
-                           (XyzzPacked<C>*)b_wsum.p);
+        hipLaunchKernelGGL(k_compact_window_sums<C>, dim3((unsigned)((nout + kBlock - 1) / kBlock), (unsigned)nwin), dim3(kBlock), 0, s, DG, DH, drowsG, drowsH, ksG, ksH,
+                           (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, (uint32_t)n0, (uint32_t)nj, lgK, nwin, bias, (uint32_t)nout, (XyzzPacked<C>*)b_wsum.p);
         BP_TRACE_SYNC(ctx, "k_compact_window_sums");
-        hipLaunchKernelGGL(k_compact_horner<C>, dim3((unsigned)((nout + kHornerQuads - 1) / kHornerQuads)), dim3(4 * kHornerQuads), 0, s,
+        hipLaunchKernelGGL(k_compact_horner<C>, dim3((unsigned)((nout + kHornerQuads / 2 - 1) / (kHornerQuads / 2))), dim3(4 * kHornerQuads), 0, s,
                            (const XyzzPacked<C>*)b_wsum.p, (uint32_t)nout, (uint32_t)nout, nwin, (const AffPacked<C>*)st->Q, (XyzzPacked<C>*)b_S.p);
         BP_TRACE_SYNC(ctx, "k_compact_horner");
         hipLaunchKernelGGL(k_digit_table_build_xyzz<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const XyzzPacked<C>*)b_S.p, (uint32_t)m, (XyzzPacked<C>*)b_mx.p);
@@ -336,23 +361,33 @@ struct Ipp {
         ipp_domain_sep(t, st->n);                                                       // :62
         size_t k = 0;
         int rc;
+        BpProf& pf = bp_prof();
+        if (bp_profile_on()) for (double& x : pf.acc) x = 0;
         while (st->n != 1) {                                                            // :68, :138
             uint8_t* L = L_out + k * 2 * kFb;
             uint8_t* R = R_out + k * 2 * kFb;
+            pf.start();
             if ((rc = round(st, L, R))) return rc;                                      // :77-104 / :145-170
+            pf.start();
             commit_point(t, "L", L);                                                    // :106-107 / :172-173
             commit_point(t, "R", R);
             Fe<F> u = challenge_scalar(t, "u");                                         // :112 / :178
             Fe<F> ui = fr_inv_fast<F>(u);                                               // :113 / :179
             uint8_t ub[32], uib[32];
             fr_to_le<F>(u, ub); fr_to_le<F>(ui, uib);
+            pf.lap(4);
+            const bool will_compact = st->compact_at && !st->compacted && st->n / 2 == st->compact_at;
             if ((rc = fold(st, ub, uib))) return rc;                                    // :115-130 / :181-188
+            pf.lap(will_compact ? 6 : 5);
             k++;
         }
         if (lg_n_out) *lg_n_out = k;
         HIPCHK(hipMemcpyAsync(a_out, st->a, 32, hipMemcpyDeviceToHost, st->ctx->stream));   // :196-201
         HIPCHK(hipMemcpyAsync(b_out, st->b, 32, hipMemcpyDeviceToHost, st->ctx->stream));
         HIPCHK(hipStreamSynchronize(st->ctx->stream));
+        if (bp_profile_on())
+            fprintf(stderr, "[bpmsm profile] ipp n0=%zu rounds=%zu us: scalar-kernel launch %.0f  msm launch %.0f  sync-wait %.0f  host-tails %.0f  transcript+inverse %.0f  fold-launch %.0f  compaction(host side) %.0f\n",
+                    (size_t)1 << k, k, pf.acc[0], pf.acc[1], pf.acc[2], pf.acc[3], pf.acc[4], pf.acc[5], pf.acc[6]);
         return BP_OK;
     }
 
@@ -785,6 +820,43 @@ int ipp_create_multi(bp_ctx* const* ctxs, size_t N, Transcript& t, const uint8_t
 }  // namespace
 
 
+// Compaction table of a vector (bp_g1vec_precompute): affine digit multiples m 2^(64 k) P_i (m = 1 .. 8, k < 4) from the rows
+// w = 64 k / c of its window-multiples table.  *out stays NULL when c does not divide 64 (the rows do not exist).
+template <class C>
+static int ctable_build_impl(bp_ctx* ctx, const bp_g1table* wt, bp_g1table** out) {
+    constexpr size_t kPt = sizeof(AffPacked<C>);
+    constexpr int K = 4;
+    const size_t n = wt->n, rows = (size_t)1 << (kSmallDigitBits - 1);
+    const int step = 64 / wt->c;
+    if ((uint64_t)rows * K * n >= ((uint64_t)1 << 31)) return BP_OK;
+    PoolBlock gathered, tmp;
+    if (!gathered.alloc(ctx, K * n * kPt) || !tmp.alloc(ctx, rows * K * n * sizeof(XyzzPacked<C>))) return BP_ERR_DEVICE;
+    bp_g1table* t = new (std::nothrow) bp_g1table();
+    if (!t) return BP_ERR_DEVICE;
+    t->pool = ctx->pool; t->device = ctx->device; t->n = n; t->c = kSmallDigitBits; t->W = (int)rows; t->digits = true; t->affine = true; t->K = K;
+    t->d = ctx->pool->get(rows * K * n * kPt, &t->cap);
+    if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+    hipStream_t s = ctx->stream;
+    for (int k = 0; k < K; k++) {
+        if ((size_t)k * step >= (size_t)wt->W) { bp_internal_table_free(t); return BP_OK; }      // (cannot happen for c | 64: W >= 256 / c)
+        if (hipMemcpyAsync((uint8_t*)gathered.p + (size_t)k * n * kPt, (const uint8_t*)wt->d + (size_t)k * step * n * kPt, n * kPt, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            bp_internal_table_free(t); return BP_ERR_DEVICE;
+        }
+    }
+    hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, (const AffPacked<C>*)gathered.p, (uint32_t)(K * n), (XyzzPacked<C>*)tmp.p);
+    int rc = hipGetLastError() == hipSuccess ? Ipp<C>::batch_to_affine(ctx, (const XyzzPacked<C>*)tmp.p, rows * K * n, (AffPacked<C>*)t->d, s, nullptr) : BP_ERR_DEVICE;
+    if (rc) { bp_internal_table_free(t); return rc; }
+    *out = t;
+    return BP_OK;
+}
+int bp_internal_ctable_build(bp_ctx* ctx, const bp_g1table* wt, bp_g1table** out) {
+    *out = nullptr;
+    if (!wt || wt->digits || wt->c <= 0 || 64 % wt->c) return BP_OK;
+    try {
+        return ctx->curve == BP_CURVE_BLS12_381 ? ctable_build_impl<Bls381>(ctx, wt, out) : ctable_build_impl<Bn254>(ctx, wt, out);
+    } catch (...) { return BP_ERR_DEVICE; }
+}
+
 extern "C" {
 
 // ---- transcript ---------------------------------------------------------------------------------------------
@@ -1143,8 +1215,14 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
         st->compact_at = !st->fold_generators && ctx->tuning.small_msm && ctx->c_override <= 0 && at >= 16 && n > at && 2 * at + 1 <= kSmallDigitMax ? at : 0;
     }
     if (st->compact_at) {
-        rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::build_original_multiples(st) : Ipp<Bn254>::build_original_multiples(st);
-        if (rc) { bp_ipp_state_free(st); return rc; }
+        const bp_g1table *cg = G->ctable ? G->ctable : G->cview, *ch = H->ctable ? H->ctable : H->cview;
+        const size_t og = G->ctable ? 0 : G->tview_off, oh = H->ctable ? 0 : H->tview_off;
+        if (cg && ch && cg->K == 4 && ch->K == 4 && og + n <= cg->n && oh + n <= ch->n && cg->device == ctx->device && ch->device == ctx->device) {
+            st->ctG = cg; st->ctH = ch; st->ctG_off = og; st->ctH_off = oh;
+        } else {
+            rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::build_original_multiples(st) : Ipp<Bn254>::build_original_multiples(st);
+            if (rc) { bp_ipp_state_free(st); return rc; }
+        }
     }
     if (!st->fold_generators && !digits && 2 * n + 1 > kSmallMsmMax) {     // smaller rounds run as ONE launch (k_small_msm): nothing for a table to merge
         rc = bp_internal_table_concat(ctx, G, 0, H, 0, n, Q_le, &st->table);
@@ -1154,6 +1232,9 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
         // that each lose the per-lane doubling chain; same-box A/B: n = 64 2.24-2.51 -> 2.04-2.07 ms per proof, n = 128 2.94-3.26 ->
         // 2.38-2.42, n = 16 1.35-1.60 -> 1.28-1.30; at n = 4 the launch costs more than two rounds save: 0.66 -> 0.72)
         rc = bp_internal_digit_table_build(ctx, st->Pall, 2 * n + 1, &st->table);
+        // ... and from ~4 terms per lane on as AFFINE rows (one batch inversion, ~60 us with its host round trip): the lanes' serial
+        // chains are then mixed additions (8M + 2S instead of 12M + 2S per term)
+        if (!rc && n >= 1024) rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::digit_table_to_affine(ctx, st->table) : Ipp<Bn254>::digit_table_to_affine(ctx, st->table);
         if (rc) { bp_ipp_state_free(st); return rc; }
     }
     *out = st;

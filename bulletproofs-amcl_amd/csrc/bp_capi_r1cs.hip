@@ -278,6 +278,8 @@ struct R1cs {
         T.keep(Hp);
         Gp->tview = G->table ? G->table : G->tview; Gp->tview_off = G->table ? 0 : G->tview_off;      // precomputed generators: the IPP's rounds inherit their tables
         Hp->tview = H->table ? H->table : H->tview; Hp->tview_off = H->table ? 0 : H->tview_off;
+        Gp->cview = G->ctable ? G->ctable : G->cview;
+        Hp->cview = H->ctable ? H->ctable : H->cview;
         size_t lg_out = 0;
         RC(bp_ipp_create(ctx, t, Q, ippin[2], ippin[3], Gp, Hp, ippin[0], ippin[1], Lp, Rp, &lg_out, ab, ab + 32));   // :567-576
         return lg_out == lg ? BP_OK : BP_ERR_DEVICE;

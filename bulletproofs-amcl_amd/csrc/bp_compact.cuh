@@ -189,11 +189,12 @@ __global__ void __launch_bounds__(64) k_digit_table_build_xyzz(const XyzzPacked<
 // Lane (o, w): output o < 2 nj (o < nj: G'_o over c_G, else H'_(o - nj) over c_H), 4-bit window w < nwin of every sub-scalar:
 //     W[w][o] = sum_{t < T} sum_{k < K} digit_(nwin k + w)(c[j + t nj]) * Row_k(P_(j + t nj))
 // with the signed digits of c + bias (bias = 0x77..7: digit = nibble - 7 in [-7, 8], as the pipeline recodes), Row_k(P_i) = 2^(4 nwin k) P_i
-// and the digit's multiple LOADED from D: D[(|d| - 1) * drows + k * npts + i], affine rows (npts = 2 n0 points: G then H).
+// and the digit's multiple LOADED from the vector's table (DG for o < nj, DH above): D[(|d| - 1) * drows + k * kstride + i], affine rows.
 // K = 1, nwin = 64: plain.  K = 4, nwin = 16: over the rows 2^(64 k) P_i of a precomputed table.
 // The loop is k_accumulate's single-path addition; the general one only for the rare doubling / cancellation.
 template <class C>
-__global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums(const AffPacked<C>* __restrict__ D, size_t drows, size_t npts, const ScalarWords* __restrict__ cG,
+__global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums(const AffPacked<C>* __restrict__ DG, const AffPacked<C>* __restrict__ DH, size_t drowsG, size_t drowsH,
+                                                                   size_t kstrideG, size_t kstrideH, const ScalarWords* __restrict__ cG,
                                                                    const ScalarWords* __restrict__ cH, uint32_t n0, uint32_t nj, int lgK, int nwin, ScalarWords bias,
                                                                    uint32_t pitch, XyzzPacked<C>* __restrict__ wsum) {
     using Fp = typename C::Fp;
@@ -201,7 +202,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums(const AffPack
     if (o >= 2 * nj) return;
     const uint32_t vec = o >= nj ? 1u : 0u, j = o - vec * nj;
     const ScalarWords* sc = vec ? cH : cG;
-    const size_t pbase = (size_t)vec * n0 + j;
+    const AffPacked<C>* D = vec ? DH : DG;                      // rows of this output's vector: D[(m - 1) * drows + k * kstride + i]
+    const size_t drows = vec ? drowsH : drowsG, npts = vec ? kstrideH : kstrideG, pbase = j;
     const uint32_t K = 1u << lgK, terms = (n0 / nj) << lgK;
     XyzzLazy<C> acc = xyzz_lazy_inf<C>();
     uint32_t e = 0;
@@ -253,43 +255,65 @@ __global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums(const AffPack
 }
 
 // ---------------------------------------------------------------------------------------------- Horner over the window sums
-// S_o = sum_w 16^w W[w][o]: per output a strictly serial chain of (nwin - 1) x (4 doublings + 1 addition); a quad of lanes per output,
-// every operation shared by its four lanes through two LDS slots (accumulator, incoming window sum).  Blocks of one wave (16
-// outputs) so that the ~2 nj / 16 waves spread over all CUs.  extra (optional): one more affine point appended as S_nout (the Q of
-// the inner-product argument), so that the digit multiples of [G' | H' | Q] come out of one array.
+// S_o = sum_w 16^w W[w][o]: per output a strictly serial chain of doublings -- 4 (nwin - 1) of them, whatever is done -- and additions.
+// A quad of lanes shares every operation through two LDS slots (accumulator, incoming window sum), and TWO quads share an output:
+// the compaction has only ~2 nj outputs, a quarter of the chip's SIMDs at one wave of 16 quads each, so the upper half of the windows
+// (quad 0: Horner, then 4 h more doublings) and the lower half (quad 1) run side by side and meet in one addition -- the critical path
+// is 4 (nwin - 1) doublings + nwin / 2 additions instead of nwin - 1.  Blocks of one wave (8 outputs).  No s_barrier: the quads of a
+// wave run different trip counts; LDS operations of one wave execute in order, the fence only keeps the compiler from moving them.
+// extra (optional): one more affine point appended as S_nout (the Q of the inner-product argument), so that the digit multiples of
+// [G' | H' | Q] come out of one array.
 constexpr int kHornerQuads = 16;
+__device__ __forceinline__ void quad_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <class C>
 __global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzPacked<C>* __restrict__ wsum, uint32_t nout, uint32_t pitch, int nwin,
                                                                      const AffPacked<C>* __restrict__ extra, XyzzPacked<C>* __restrict__ out) {
     using Fp = typename C::Fp;
     constexpr int NW = Fp::NW;
     __shared__ XyzzPacked<C> lds[2 * kHornerQuads];
-    const int quad = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3;
-    const uint32_t o = blockIdx.x * kHornerQuads + quad;
-    const uint32_t oo = o < nout ? o : nout - 1;                 // a quad past the end shadows the last output (uniform trip counts), stores nothing
+    const int quad = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3, seg = quad & 1;
+    const uint32_t o = blockIdx.x * (kHornerQuads / 2) + (quad >> 1);
+    const uint32_t oo = o < nout ? o : nout - 1;                 // a pair of quads past the end shadows the last output and stores nothing
+    const int h = nwin / 2;                                      // quad 0: windows [h, nwin), quad 1: windows [0, h)
+    const int w_hi = seg ? h - 1 : nwin - 1, w_lo = seg ? 0 : h;
     uint32_t* A = (uint32_t*)&lds[2 * quad];
     uint32_t* B = (uint32_t*)&lds[2 * quad + 1];
-    {   // lane q moves field q
-        const uint32_t* src = (const uint32_t*)&wsum[(size_t)(nwin - 1) * pitch + oo];
+    if (w_hi >= w_lo) {   // lane q moves field q
+        const uint32_t* src = (const uint32_t*)&wsum[(size_t)w_hi * pitch + oo];
         for (int i = 0; i < NW; i++) A[q * NW + i] = src[q * NW + i];
+    } else {
+        for (int i = 0; i < NW; i++) A[q * NW + i] = 0;          // (nwin = 1: no lower half) the identity
     }
-    __syncthreads();
+    quad_lds_fence();
 #pragma unroll 1
-    for (int w = nwin - 2; w >= 0; w--) {
+    for (int w = w_hi - 1; w >= w_lo; w--) {
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
             xyzz_lazy_dbl_quad<C>(lds, 2 * quad, q);
-            __syncthreads();
+            quad_lds_fence();
         }
         const uint32_t* src = (const uint32_t*)&wsum[(size_t)w * pitch + oo];
         for (int i = 0; i < NW; i++) B[q * NW + i] = src[q * NW + i];
-        __syncthreads();
+        quad_lds_fence();
         xyzz_lazy_add_quad<C>(lds, 2 * quad, 2 * quad + 1, q);
-        __syncthreads();
+        quad_lds_fence();
     }
-    if (o < nout) {
-        uint32_t* dst = (uint32_t*)&out[o];
-        for (int i = 0; i < NW; i++) dst[q * NW + i] = A[q * NW + i];
+    if (seg == 0) {
+#pragma unroll 1
+        for (int k = 0; k < 4 * h; k++) {                        // the upper half's weight 16^h
+            xyzz_lazy_dbl_quad<C>(lds, 2 * quad, q);
+            quad_lds_fence();
+        }
+        xyzz_lazy_add_quad<C>(lds, 2 * quad, 2 * quad + 2, q);   // + the lower half (its quad finished long ago: same wave, in order)
+        quad_lds_fence();
+        if (o < nout) {
+            uint32_t* dst = (uint32_t*)&out[o];
+            for (int i = 0; i < NW; i++) dst[q * NW + i] = A[q * NW + i];
+        }
     }
     if (extra && blockIdx.x == 0 && threadIdx.x == 0) {
         const Aff<C> p = aff_unpack(*extra);

@@ -20,6 +20,22 @@
 // can change what the pipeline does is a validated per-context knob (bp_ctx_set_tuning, include/bpmsm.h).
 static inline bool bp_verbose_on() { static const bool on = getenv("BP_VERBOSE") != nullptr; return on; }
 static inline bool bp_trace_on() { static const bool on = getenv("BP_TRACE") != nullptr; return on; }
+// BP_PROFILE (diagnostic, like BP_TRACE): wall-clock accumulators around the host-side steps of a proof, printed to stderr by
+// bp_ipp_create.  Slots: see bp_prof_names in bp_capi_ipp.hip.
+static inline bool bp_profile_on() { static const bool on = getenv("BP_PROFILE") != nullptr; return on; }
+#include <chrono>
+struct BpProf {
+    double acc[12] = {};
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (bp_profile_on()) t0 = std::chrono::steady_clock::now(); }
+    void lap(int slot) {
+        if (!bp_profile_on()) return;
+        auto t1 = std::chrono::steady_clock::now();
+        acc[slot] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t0 = t1;
+    }
+};
+inline BpProf& bp_prof() { static thread_local BpProf p; return p; }
 
 #define HIPCHK(expr)                                                                                         \
     do {                                                                                                     \
@@ -189,6 +205,11 @@ struct bp_g1vec {
     // G[0..pn)): lets bp_internal_table_concat copy the rows it needs; never freed through the view
     const struct bp_g1table* tview = nullptr;
     size_t tview_off = 0;
+    // compaction table (round 4; built by bp_g1vec_precompute when the window width divides 64): affine digit multiples
+    // m 2^(64 k) P_i, m = 1 .. 8, k < 4 -- what the inner-product prover's generator compaction (bp_compact.cuh) needs to cut its Horner
+    // chain from 252 to 60 doublings.  Owned like `table`; `cview` is the view form (same offset as tview_off).
+    struct bp_g1table* ctable = nullptr;
+    const struct bp_g1table* cview = nullptr;
 };
 struct bp_frvec {
     bp_ctx* ctx;
@@ -214,9 +235,12 @@ struct bp_g1table {
     // round is <= kSmallMsmMax terms: the lanes then load their digit's multiple instead of computing it (library-internal).
     bool digits = false;
     bool affine = false;     // digits only: the rows are canonical AFFINE points (AffPacked) instead of lazy XYZZ (bp_compact.cuh: batch conversion)
+    int K = 1;               // digits only: sub-rows per point (compaction table: K = 4, rows[(m - 1) * K * n + k * n + i] = m 2^(64 k) P_i)
 };
 extern "C" void bp_internal_table_free(bp_g1table* t);
 int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out);
+// compaction table of a vector from its window-multiples table (bp_capi_ipp.hip); *out stays NULL when the width does not divide 64
+int bp_internal_ctable_build(bp_ctx* ctx, const bp_g1table* wt, bp_g1table** out);
 
 static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
 static inline bool curve_ok(int curve) { return curve == BP_CURVE_BLS12_381 || curve == BP_CURVE_BN254; }

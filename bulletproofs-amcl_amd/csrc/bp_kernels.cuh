@@ -864,17 +864,59 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
     const int cw = tab.cw[w], off = tab.off[w];
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
     // grid.y blocks share a window's terms (block b: terms b * 256 + lane, stride 256 * grid.y) and leave one record each
+    if (MODE == 2) {
+        // the lane's serial chain with k_accumulate's single-path mixed addition: the accumulator starts as the first term with a
+        // non-zero digit (a scan of digits only, so that every lane enters the addition loop together), the general addition takes
+        // the rare doubling / cancellation
+        using Fp = typename C::Fp;
+        const uint32_t stride = kBlock * gridDim.y;
+        uint32_t t = blockIdx.y * kBlock + threadIdx.x;
+        auto fetch = [&](uint32_t tt, Aff<C>& p, bool& neg) -> bool {
+            uint64_t q[4];
+            add256(q, (set ? sc2 : sc1)[tt], tab.bias);
+            const int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
+            if (d == 0) return false;
+            p = aff_unpack(((const AffPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n + tt]);
+            neg = d < 0;
+            return !aff_is_inf(p);
+        };
+        auto restart = [&]() {
+            Aff<C> p; bool neg;
+            while (t < n && !fetch(t, p, neg)) t += stride;
+            if (t < n) {
+                if (neg) p.y = fe_neg(p.y);
+                mine = xyzz_lazy_from_strict(xyzz_from_aff(p));
+                t += stride;
+            }
+        };
+        restart();
+        while (t < n) {
+            while (t < n) {
+                Aff<C> p; bool neg;
+                if (!fetch(t, p, neg)) { t += stride; continue; }
+                FeB<Fp, 2> qy = feb_widen<2>(feb_from_strict<Fp>(p.y));
+                if (neg) qy = feb_neg_canonical<Fp>(p.y);
+                if (!xyzz_lazy_add_aff_fast(mine, feb_from_strict<Fp>(p.x), qy)) break;
+                t += stride;
+            }
+            if (t < n) {
+                Aff<C> p; bool neg;
+                if (fetch(t, p, neg)) {
+                    if (neg) p.y = fe_neg(p.y);
+                    xyzz_lazy_add_aff(mine, p);
+                }
+                t += stride;
+                if (mine.inf) restart();
+            }
+        }
+    } else {
 #pragma unroll 1
     for (uint32_t t = blockIdx.y * kBlock + threadIdx.x; t < n; t += kBlock * gridDim.y) {      // kSmallMsmMax / kBlock terms per lane at most (16 with mult)
         uint64_t q[4];
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
         int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
         if (d == 0) continue;
-        if (MODE == 2) {
-            Aff<C> p = aff_unpack(((const AffPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n + t]);
-            if (d < 0) p.y = fe_neg(p.y);
-            xyzz_lazy_add_aff(mine, p);
-        } else if (MODE == 1) {
+        if (MODE == 1) {
             XyzzLazy<C> acc = xyzz_lazy_unpack(((const XyzzPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n + t]);
             if (d < 0 && !acc.inf) acc.y = feb_neg<4>(acc.y);
             mine = xyzz_lazy_add(mine, acc);
@@ -889,6 +931,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
             }
             mine = xyzz_lazy_add(mine, acc);
         }
+    }
     }
     mine = block_tree_sum_quad<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
     if (threadIdx.x == 0) window_sum[tab.roff[w] + blockIdx.y] = xyzz_lazy_pack(mine);

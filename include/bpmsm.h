@@ -126,10 +126,14 @@ int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out
  * runs over one window instead of ~16 and the host tail shrinks from ~255 doublings to c.  For the generators of a proof
  * system -- public parameters reused by every proof (/root/reference src/r1cs/prover.rs:347-362, src/ipp.rs:91,104,158,170).
  * Results are bit-identical with and without a table.  window_bits: 2..16, 0 = chosen from n; memory = ceil((fr_bits+1)/c) x the
- * vector.  The caller must not modify the vector's points afterwards (bp_g1vec_device_ptr writers): the table would be stale. */
+ * vector.  The caller must not modify the vector's points afterwards (bp_g1vec_device_ptr writers): the table would be stale.
+ * Round 4: when window_bits divides 64 (16, 8, 4, 2) the call also builds the vector's COMPACTION TABLE -- the affine digit
+ * multiples m 2^(64 k) P_i, m = 1 .. 8, k < 4 (32 more rows per point) -- which lets the inner-product prover materialise its folded
+ * generators with a Horner chain of 60 doublings instead of 252 (BP_TUNE_COMPACT_AT).  ctx must be on the vector's device
+ * (BP_ERR_ARG otherwise); the call returns when the tables are complete, so any context may use them afterwards. */
 int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits);
 int bp_g1vec_drop_table(bp_g1vec* v);
-/* window width, number of windows and bytes of the vector's table (all 0 when it has none) */
+/* window width, number of windows and bytes of the vector's tables (window multiples + compaction table; all 0 when it has none) */
 int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_t* bytes);
 /* out[i] = k[i] * G.  Batched form of `&G1::generator() * &FieldElement` (src/utils/mod.rs:34); used to build
  * synthetic generator vectors on the device. */

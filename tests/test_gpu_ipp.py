@@ -268,6 +268,53 @@ def test_ipp_generator_compaction_vs_oracle(bp, ctxs, name, n, at, unit_gf):
     assert (plain.L, plain.R, plain.a, plain.b) == want
     assert (proof.L, proof.R, proof.a, proof.b) == want
     assert (Ls, Rs, fa, fb) == want
+    # ... and over the vectors' COMPACTION TABLES (bp_g1vec_precompute with a width that divides 64: rows 2^(64 k) P, Horner chain of 60 doublings)
+    try:
+        Gv.precompute(16); Hv.precompute(16)
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, at)
+        tabled = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        Hv.precompute(8)                                 # tables of different widths: both still have a compaction table
+        mixed = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        Hv.precompute(12)                                # 12 does not divide 64: H has no compaction table, the prover builds the multiples itself
+        none = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    finally:
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, 0)
+        Gv.drop_table(); Hv.drop_table()
+    for pr in (tabled, mixed, none):
+        assert (pr.L, pr.R, pr.a, pr.b) == want
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+
+
+@pytest.mark.parametrize("name,n", [("bls12_381", 4096), ("bn254", 4096), ("bls12_381", 8192), ("bn254", 8192), ("bn254", 16384)])
+def test_ipp_single_launch_boundary_and_compaction_sizes_vs_oracle(bp, ctxs, name, n):
+    """kSmallDigitMax = 8193 makes n = 4096 the last proof whose every round is a single launch over digit multiples
+    (BASELINE config 5's size) and n = 8192 the first that starts on the bucket pipeline -- and, since round 4, the first that COMPACTS
+    its generators (after one round; n = 16384 after two).  Proof bytes = the (threaded) C oracle's, with and without window /
+    compaction tables, compaction on and off."""
+    import os
+    ctx = ctxs[name]
+    cid = ctx.curve
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 51000 + n, unit_gf=False)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes(), n)
+    finally:
+        O.set_threads(1)
+    assert rc == 0
+    proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    assert (proof.L, proof.R, proof.a, proof.b) == want
+    try:
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, 1)
+        off = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, 0)
+        Gv.precompute(16); Hv.precompute(16)
+        tabled = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+    finally:
+        ctx.set_tuning(bp.TUNE_COMPACT_AT, 0)
+        Gv.drop_table(); Hv.drop_table()
+    assert (off.L, off.R, off.a, off.b) == want
+    assert (tabled.L, tabled.R, tabled.a, tabled.b) == want
     P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
     bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
 
@@ -396,13 +443,15 @@ def test_ipp_round_api_with_external_transcript(bp, ctxs, name, prover_mode):
 
 
 def test_ipp_bn254_n4096_config5(bp, ctxs):
-    """BASELINE config 5: BN254 IPP at n = 2^12 -- create on the GPU, verify on the GPU, cross-verify with the oracle."""
+    """BASELINE config 5: BN254 IPP at n = 2^12 -- proof bytes equal the oracle's; verify on the GPU, cross-verify with the oracle."""
     ctx = ctxs["bn254"]
     cid = ctx.curve
     n = 4096
     Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 12000)
     proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
     assert proof.lg_n == 12
+    rc, want = O.ipp_create(cid, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes(), n)
+    assert rc == 0 and (proof.L, proof.R, proof.a, proof.b) == want          # bit-exact at config 5's size (VERDICT r3 #4)
     P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
     bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
     assert O.ipp_verify(cid, O.Transcript(b"innerproduct"), n, Gf.to_bytes(), Hf.to_bytes(), P, Q, Gv.to_bytes(), Hv.to_bytes(), proof.a, proof.b,
