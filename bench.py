@@ -122,6 +122,33 @@ def size_sweep(bp, ctx, curve, info, unit_bytes, lgs=(16, 17, 18, 19, 20, 21, 22
     return out
 
 
+def h2d_headline(bp, ctx, torch, pts, s_bytes, n, expect, steps):
+    """The headline MSM with its scalars arriving from the HOST every step: pageable memory (what a Rust Vec is) and page-locked
+    memory (what a binding that owns its staging buffer can offer).  Upload = bp_frvec_upload: H2D copy + the canonicity check."""
+    import numpy as np
+
+    def run(src):
+        sv2 = bp.FieldElementVector.from_bytes(ctx, src, n)
+        got = pts.multi_scalar_mul_var_time(sv2)
+        sv2.free()
+        return got
+
+    res = {"workload": "the 2^%d-point MSM of `value` with its %d MiB of scalars uploaded inside every step" % (n.bit_length() - 1, 32 * n >> 20)}
+    pinned = torch.from_numpy(np.frombuffer(s_bytes, dtype=np.uint8).copy()).pin_memory()
+    for name, src in (("pageable", s_bytes), ("pinned", bp.HostPtr(pinned.data_ptr(), 32 * n))):
+        ok = run(src) == expect
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = run(src)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"ms_per_step": dt * 1e3, "value": n / dt if (ok and got == expect) else None, "unit": "scalar-muls/s", "verified": bool(ok and got == expect)}
+    res["ms_per_step"] = res["pinned"]["ms_per_step"]
+    res["value"] = res["pinned"]["value"]
+    return res
+
+
 def strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=22, steps=5, warmup=1):
     """BASELINE config 4 inside the weak run: 2^22 points IN TOTAL split by index range over the ranks, timed like the main value
     (barrier + synchronize on both sides, max over ranks) and verified against the oracle on rank 0."""
@@ -197,6 +224,7 @@ def main():
     ap.add_argument("--extras", action="store_true", help="emit the extra keys although --lg-n is not the headline size (tests)")
     ap.add_argument("--sweep-max-lg", type=int, default=22, help="largest size of the N = 1 sweep (tests shrink it)")
     ap.add_argument("--strong-lg", type=int, default=22, help="log2 of the total size of the N > 1 strong-scaling extra (tests shrink it)")
+    ap.add_argument("--configs-small", action="store_true", help="shrunk sizes for the \"configs\" extra (cfg1 / cfg3_e2e / cfg5; tests)")
     ap.add_argument("--overlap", action="store_true",
                     help="also time the same MSMs with two in flight (extra field; off by default so that rocprofv3 averages of the default "
                          "command are not mixed with concurrently running kernels)")
@@ -458,6 +486,13 @@ def main():
     extras = not args.no_extras and not args.strong and args.curve == "bls12_381" and (args.lg_n == 20 or args.extras)
     if extras and world == 1 and not failed:
         out["sweep"] = size_sweep(bp, ctx, curve, info, unit_bytes, lgs=tuple(range(min(16, args.sweep_max_lg), args.sweep_max_lg + 1)))
+        # The reference's call site hands over HOST scalars with every call (multi_scalar_mul_var_time(&scalars), src/ipp.rs:251-253):
+        # the same MSM with the 32 n bytes of scalars uploaded inside the step.  Never `value`.
+        out["with_scalar_h2d"] = h2d_headline(bp, ctx, torch, pts, s_bytes, n, result, max(3, min(args.steps, 10)))
+        pts.free(); sv.free(); kv.free()
+        ctx.trim()
+        import bench_configs as BC
+        out["configs"] = BC.driver_configs(small=args.configs_small)
     if extras and world > 1:
         st = strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=args.strong_lg)
         if rank == 0:

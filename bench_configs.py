@@ -302,6 +302,111 @@ def cfg3_e2e():
     return out
 
 
+def median_of(fn, reps=5):
+    ts, out = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), out
+
+
+def driver_configs(small=False, reps=5):
+    """BASELINE configs 1, 3 and 5 for the driver's ONE bench line (bench.py puts the result under "configs"): the
+    callers the headline MSM stands for -- IPP::create_ipp / verify_ipp (/root/reference src/ipp.rs:35-260) and Prover::prove /
+    Verifier::verify (src/r1cs/prover.rs:322-593, tests/multiple_constraint_systems.rs:25).  Medians of `reps` runs, inputs resident,
+    every proof compared byte for byte with the C oracle (the checker: threaded for config 3).  small: shrunk sizes for the contract
+    test (tests/test_gpu_bench_contract.py), same keys."""
+    import r1cs_twin as R1
+    out = {}
+    thr = min(32, os.cpu_count() or 1)
+
+    def ipp_leg(ctx, n, seed):
+        Gv, Hv, Q, Gf, Hf, a, b, P = ipp_instance(ctx, n, seed)
+        bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        tc, proof = median_of(lambda: bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b), reps)
+        tv, _ = median_of(lambda: bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R), reps)
+        O.set_threads(thr)
+        try:
+            rc, want = O.ipp_create(ctx.curve, O.Transcript(b"innerproduct"), Q, Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes(), n)
+        finally:
+            O.set_threads(1)
+        return {"n": n, "create_ms": tc * 1e3, "verify_ms": tv * 1e3, "proof_bit_exact_vs_oracle": bool(rc == 0 and (proof.L, proof.R, proof.a, proof.b) == want)}
+
+    # ---- config 1: IPP create + verify at n = 64, BLS12-381
+    ctx = bp.Context(bp.BLS12_381, 0)
+    out["cfg1"] = ipp_leg(ctx, 64, 100)
+    ctx.close()
+
+    # ---- config 3 end to end: 1024 chained 32-bit bound checks = 2^16 gates, bp_r1cs_prove / bp_r1cs_verify
+    ctx = bp.Context(bp.BLS12_381, 0)
+    info = bp.curve_info(ctx.curve)
+    r = ctx.r
+    checks, bits = (8, 16) if small else (1024, 32)
+    terms, nq, aL, aR, aO, v = bound_check_chain(r, checks, bits, np.random.default_rng(2024))
+    n, m = len(aL), len(v)
+    gens_ = R1.Generators(ctx, n)
+    plan = bp.R1CSPlan(ctx, terms, nq, n, m)
+    le = lambda xs: b"".join(int(x).to_bytes(32, "little") for x in xs)
+    fe = lambda b_, k: bp.FieldElementVector.from_bytes(ctx, b_, k)
+    vb = random_scalars(r, info.fr_bits, m, 9000)
+    V = gens_.commit_many(v, [int.from_bytes(vb[32 * j:32 * j + 32], "little") for j in range(m)])
+    Vb = b"".join(V)
+    aLb, aRb, aOb = le(aL), le(aR), le(aO)
+    sLb, sRb, blb = random_scalars(r, info.fr_bits, n, 9100), random_scalars(r, info.fr_bits, n, 9101), random_scalars(r, info.fr_bits, 8, 9200)
+    dAL, dAR, dAO, dVB, dSL, dSR = fe(aLb, n), fe(aRb, n), fe(aOb, n), fe(vb, m), fe(sLb, n), fe(sRb, n)
+    prove = lambda: bp.r1cs_prove(ctx, R1.start_transcript(ctx, b"cfg3", V), plan, gens_.G, gens_.H, gens_.g, gens_.h, dAL, dAR, dAO, dVB, dSL, dSR, blb)
+
+    def verify(proof):
+        try:
+            bp.r1cs_verify(ctx, R1.start_transcript(ctx, b"cfg3", V), plan, gens_.G, gens_.H, gens_.g, gens_.h, Vb, n, proof, os.urandom(31) + b"\0")
+            return True
+        except (bp.VerificationError, bp.ArgError):
+            return False
+
+    proof = prove()
+    tp, proof = median_of(prove, reps)
+    tv, ok = median_of(lambda: verify(proof), reps)
+    bad = bytearray(proof)
+    bad[11 * ctx.point_bytes] ^= 1                                  # t_x
+    rejected = not verify(bytes(bad))
+    O.set_threads(thr)
+    try:
+        T = O.R1CSTerms(terms, nq, n, m)
+        rc, want = O.r1cs_prove(ctx.curve, O.r1cs_start_transcript(ctx.curve, b"cfg3", V), T, gens_.g, gens_.h, gens_.G.to_bytes(), gens_.H.to_bytes(), n,
+                                aLb, aRb, aOb, vb, sLb, sRb, blb)
+    finally:
+        O.set_threads(1)
+    t0 = time.perf_counter()
+    gens_.G.precompute(16); gens_.H.precompute(16); ctx.synchronize()
+    t_tab = time.perf_counter() - t0
+    tpt, proof_t = median_of(prove, reps)
+    gens_.G.drop_table(); gens_.H.drop_table()
+    out["cfg3_e2e"] = {"gates": n, "constraints": nq, "committed": m, "prove_ms": tp * 1e3, "verify_ms": tv * 1e3, "accepted": bool(ok),
+                       "tampered_rejected": bool(rejected), "bytes_equal_oracle": bool(rc == 0 and proof == want), "proof_bytes": len(proof),
+                       "with_precomputed_generator_tables": {"prove_ms": tpt * 1e3, "same_proof_bytes": bool(proof_t == proof),
+                                                             "tables_built_once_ms": t_tab * 1e3}}
+    plan.free()
+    ctx.close()
+
+    # ---- config 5: BN254 2^20 MSM + IPP at n = 2^12
+    ctx = bp.Context(bp.BN254, 0)
+    info = bp.curve_info(ctx.curve)
+    n5 = 1 << (14 if small else 20)
+    Pv, pk = gens(ctx, n5, 500)
+    sb = random_scalars(ctx.r, info.fr_bits, n5, 501)
+    sv = bp.FieldElementVector.from_bytes(ctx, sb, n5)
+    Pv.multi_scalar_mul_var_time(sv)
+    tm, got = median_of(lambda: Pv.multi_scalar_mul_var_time(sv), max(reps, 10))
+    want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, pk, sb, n5), O.generator(ctx.curve))
+    Pv.free()
+    ipp5 = ipp_leg(ctx, 64 if small else 4096, 510)
+    out["cfg5"] = {"msm_n": n5, "msm_ms": tm * 1e3, "msm_scalar_muls_per_s": n5 / tm, "msm_verified": bool(got == want), "ipp_n": ipp5["n"],
+                   "ipp_create_ms": ipp5["create_ms"], "ipp_verify_ms": ipp5["verify_ms"], "proof_bit_exact_vs_oracle": ipp5["proof_bit_exact_vs_oracle"]}
+    ctx.close()
+    return out
+
+
 def generators():
     """get_generators("G", n) -- SURVEY 8f-1; the reference calls generator creation "very slow"
     (src/r1cs/gadgets/sparse_merkle_tree_8_ary.rs:255).  CPU figure = the C oracle on a bounded sample."""

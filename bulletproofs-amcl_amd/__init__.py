@@ -267,6 +267,13 @@ class Context:
         return [buf[i] for i in range(k)]
 
 
+class HostPtr:
+    """A raw host address + length handed to the upload calls instead of a bytes object (no copy on the Python side)."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+
+
 class G1Vector:
     """amcl_wrapper::group_elem_g1::G1Vector, resident in HBM."""
 
@@ -413,8 +420,10 @@ class FieldElementVector:
 
     @classmethod
     def from_bytes(cls, ctx, data, n):
+        """data: bytes-like, or a HostPtr (a caller-owned host buffer -- e.g. page-locked -- passed to bp_frvec_upload as it is)"""
         h = ctypes.c_void_p()
-        _check(lib().bp_frvec_upload(ctx.h, bytes(data), n, ctypes.byref(h)), "bp_frvec_upload")
+        src = ctypes.cast(ctypes.c_void_p(data.ptr), _U8P) if isinstance(data, HostPtr) else bytes(data)
+        _check(lib().bp_frvec_upload(ctx.h, src, n, ctypes.byref(h)), "bp_frvec_upload")
         return cls(ctx, h)
 
     @classmethod

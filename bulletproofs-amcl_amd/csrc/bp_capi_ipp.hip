@@ -153,8 +153,15 @@ struct Ipp {
     // stay with the state until it is freed (the pool recycles in the order of the context's stream only).
     static int batch_to_affine(bp_ctx* ctx, const XyzzPacked<C>* in, size_t n, AffPacked<C>* out, hipStream_t s, bp_ipp_state* hold) {
         if (n == 0) return BP_OK;
+        constexpr size_t kChunk = (size_t)kBlock * kBaiMidPer * kBaiTile;       // what one middle block covers (4 M elements): larger arrays in chunks, an inversion each
+        if (n > kChunk) {
+            for (size_t o = 0; o < n; o += kChunk) {
+                int rc = batch_to_affine(ctx, in + o, n - o < kChunk ? n - o : kChunk, out + o, s, hold);
+                if (rc) return rc;
+            }
+            return BP_OK;
+        }
         const size_t nb = (n + kBaiTile - 1) / kBaiTile;
-        if (nb > (size_t)kBlock * kBaiMidPer) return BP_ERR_ARG;
         PoolBlock b_prod, b_inv;
         void *p_prod = nullptr, *p_inv = nullptr;
         if (hold) {

@@ -29,6 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libbpmsm.so is built with -fvisibility=hidden: exactly the functions declared between this push and the pop at the end of the
+ * header are exported (tests/test_capi_cpu.py compares `nm -D` with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BP_OK 0
 #define BP_ERR_LENGTH 1
@@ -444,6 +449,9 @@ int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le,
                              const uint8_t* u_le32, const uint8_t* a_le32, const uint8_t* b_le32, uint8_t* u_sq_out, uint8_t* u_inv_sq_out,
                              bp_frvec** g_scalars, bp_frvec** h_scalars);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -15,9 +15,12 @@
 //!   3 fr_from_bytes     FieldElement::from(&[u8; MODBYTES]) of 0xff..ff (reduction mod r) and of 1
 //!   4 from_msg_hash     G1::from_msg_hash for the messages of tests/golden/hash_to_g1.json; get_generators("G"/"H", 12)
 //!   5 generator         G1::generator() (which BN254 this is), curve order
-//!   7 transcript        the challenge bytes after committing a point and a scalar with the crate's TranscriptProtocol
+//!   7 transcript        the challenge bytes after committing a point and a scalar the way the crate's TranscriptProtocol does
+//!                       (src/transcript.rs:47-60; the module is PRIVATE -- `mod transcript;`, src/lib.rs:23 -- so an integration test
+//!                       cannot import the trait: its three one-line methods are restated below on merlin::Transcript, verbatim)
 //!   8 ipp               the reference's own test_ipp instance (a = 1..4, b = 5..8, hashed generators) with y_inv FIXED to the value of
 //!                       tests/golden/ipp.json "test_ipp_n4_hashed_generators": L, R, a, b and a transcript challenge afterwards
+//!   9 ipp (n = 64)      BASELINE config 1's size: a = 1..64, b = 65..128, same construction, fixture "pin9_n64_hashed_generators"
 #![allow(non_snake_case)]
 extern crate amcl_wrapper;
 extern crate bulletproofs_amcl as bp;
@@ -28,9 +31,18 @@ use amcl_wrapper::field_elem::{FieldElement, FieldElementVector};
 use amcl_wrapper::group_elem::{GroupElement, GroupElementVector};
 use amcl_wrapper::group_elem_g1::{G1Vector, G1};
 use bp::ipp::IPP;
-use bp::transcript::TranscriptProtocol;
 use bp::utils::get_generators;
 use merlin::Transcript;
+
+// bulletproofs_amcl::transcript is a private module (src/lib.rs:23).  What TranscriptProtocol does for these three calls, restated from
+// src/transcript.rs:47-60 on the public merlin API (create_ipp itself uses the crate's own implementation internally):
+fn t_commit_point(t: &mut Transcript, label: &'static [u8], p: &G1) { t.append_message(label, &p.to_bytes()); }              // :51-53
+fn t_commit_scalar(t: &mut Transcript, label: &'static [u8], s: &FieldElement) { t.append_message(label, &s.to_bytes()); }  // :47-49
+fn t_challenge_scalar(t: &mut Transcript, label: &'static [u8]) -> FieldElement {                                            // :55-60
+    let mut buf = [0u8; MODBYTES];
+    t.challenge_bytes(label, &mut buf);
+    FieldElement::from(&buf)
+}
 
 #[cfg(feature = "bls381")]
 const CURVE: &str = "bls12_381";
@@ -110,25 +122,18 @@ fn pin_5_generator_and_order() {
 #[test]
 fn pin_7_transcript() {
     let mut t = Transcript::new(b"pin");
-    t.commit_point(b"P", &G1::generator());
-    t.commit_scalar(b"s", &FieldElement::from(5u64));
-    let c = t.challenge_scalar(b"c");
+    t_commit_point(&mut t, b"P", &G1::generator());
+    t_commit_scalar(&mut t, b"s", &FieldElement::from(5u64));
+    let c = t_challenge_scalar(&mut t, b"c");
     let mut raw = [0u8; 32];
     t.challenge_bytes(b"after", &mut raw);
     println!("PIN {{\"item\": \"transcript\", \"curve\": \"{}\", \"challenge\": \"{}\", \"after\": \"{}\"}}", CURVE, fr_le(&c), hx(&raw));
 }
 
-#[test]
-fn pin_8_reference_test_ipp() {
-    // y_inv of tests/golden/ipp.json, case "test_ipp_n4_hashed_generators" (H_factors[1]); paste the value for the curve under test
-    #[cfg(feature = "bls381")]
-    let y_inv_le = "PASTE: tests/golden/ipp.json -> bls12_381 -> test_ipp_n4_hashed_generators -> H_factors[1]";
-    #[cfg(feature = "bn254")]
-    let y_inv_le = "PASTE: tests/golden/ipp.json -> bn254 -> test_ipp_n4_hashed_generators -> H_factors[1]";
-    if y_inv_le.starts_with("PASTE") { println!("PIN {{\"item\": \"ipp\", \"curve\": \"{}\", \"skipped\": \"y_inv not pasted\"}}", CURVE); return; }
-    let n = 4;
-    let a: FieldElementVector = vec![1u8, 2, 3, 4].iter().map(|i| FieldElement::from(*i)).collect::<Vec<FieldElement>>().into();
-    let b: FieldElementVector = vec![5u8, 6, 7, 8].iter().map(|i| FieldElement::from(*i)).collect::<Vec<FieldElement>>().into();
+/// create_ipp on the reference's own test construction (src/ipp.rs:340-350) with a = first..first+n-1, b = first+n.., y_inv fixed
+fn pin_ipp(name: &str, n: usize, y_inv_le: &str) {
+    let a: FieldElementVector = (1..=n as u64).map(FieldElement::from).collect::<Vec<FieldElement>>().into();
+    let b: FieldElementVector = ((n as u64 + 1)..=(2 * n as u64)).map(FieldElement::from).collect::<Vec<FieldElement>>().into();
     let G: G1Vector = get_generators("g", n).into();
     let H: G1Vector = get_generators("h", n).into();
     let Q = G1::from_msg_hash("Q".as_bytes());
@@ -142,6 +147,22 @@ fn pin_8_reference_test_ipp() {
     let l: Vec<String> = proof.L.iter().map(|p| format!("\"{}\"", g1_le(p))).collect();
     let r: Vec<String> = proof.R.iter().map(|p| format!("\"{}\"", g1_le(p))).collect();
     let l_amcl: Vec<String> = proof.L.iter().map(|p| format!("\"{}\"", hx(&p.to_bytes()))).collect();
-    println!("PIN {{\"item\": \"ipp\", \"curve\": \"{}\", \"name\": \"test_ipp_n4_hashed_generators\", \"L\": [{}], \"R\": [{}], \"L_amcl\": [{}], \"a_out\": \"{}\", \"b_out\": \"{}\", \"transcript_after\": \"{}\"}}",
-             CURVE, l.join(", "), r.join(", "), l_amcl.join(", "), fr_le(&proof.a), fr_le(&proof.b), hx(&after));
+    println!("PIN {{\"item\": \"ipp\", \"curve\": \"{}\", \"name\": \"{}\", \"L\": [{}], \"R\": [{}], \"L_amcl\": [{}], \"a_out\": \"{}\", \"b_out\": \"{}\", \"transcript_after\": \"{}\"}}",
+             CURVE, name, l.join(", "), r.join(", "), l_amcl.join(", "), fr_le(&proof.a), fr_le(&proof.b), hx(&after));
 }
+
+// y_inv = H_factors[1] of the two fixtures in tests/golden/ipp.json (32-byte little-endian scalars)
+#[cfg(feature = "bls381")]
+const Y_INV_N4: &str = "03f67c80e40d48791d484313f1fb59636d5a80b874162c904bca2f0783c74960";
+#[cfg(feature = "bls381")]
+const Y_INV_N64: &str = "d12cd97125e804ff2a8fe223c436985a511819b893deec68c5dcd0a7e727411d";
+#[cfg(feature = "bn254")]
+const Y_INV_N4: &str = "b6f9e5e1e5c477893a62455c36db9157953364b455773fb289a2470863f1a815";
+#[cfg(feature = "bn254")]
+const Y_INV_N64: &str = "aa35345252185e0c2f8074cdb949bfbac1fa11473befa7ddf9b59a4323b23c15";
+
+#[test]
+fn pin_8_reference_test_ipp() { pin_ipp("test_ipp_n4_hashed_generators", 4, Y_INV_N4); }      // a = 1..4, b = 5..8: src/ipp.rs:325-389
+
+#[test]
+fn pin_9_ipp_n64() { pin_ipp("pin9_n64_hashed_generators", 64, Y_INV_N64); }                   // BASELINE config 1's size

@@ -197,6 +197,9 @@ def gen_ipp():
             # the same unit test with its own generator construction (src/ipp.rs:340-342): get_generators("g"/"h", n),
             # Q = G1::from_msg_hash("Q") -- kept last so that the cases above keep their RNG stream
             ("test_ipp_n4_hashed_generators", 4, [1, 2, 3, 4], [5, 6, 7, 8], True),
+            # BASELINE config 1's size with inputs anybody can rebuild from the reference's API alone (integration/rust/pin_fixtures.rs,
+            # pin_9): a = 1..64, b = 65..128, get_generators("g"/"h", 64), Q = from_msg_hash("Q"), H_factors = vandermonde(y_inv)
+            ("pin9_n64_hashed_generators", 64, list(range(1, 65)), list(range(65, 129)), True),
         ):
             if a is None:
                 a = [rng.scalar(c) for _ in range(n)]

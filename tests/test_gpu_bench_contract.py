@@ -38,13 +38,25 @@ def test_bench_extras_sweep_and_strong_keys():
     one-GPU box in rehearsal mode).  Every entry is verified against the oracle."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lg-n", "14", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--extras",
-                        "--sweep-max-lg", "17"], capture_output=True, text=True, timeout=600, env=env)
+                        "--sweep-max-lg", "17", "--configs-small"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     sw = d["sweep"]
     assert sorted(sw) == ["2^16", "2^17"]
     for e in sw.values():
         assert e["verified"] is True and e["ms"] > 0 and e["scalar_muls_per_s"] > 0 and e["algorithmic_GBs"] > 0
+    # VERDICT r3 #2: the other BASELINE configs and the PCIe-inclusive headline ride in the same line (shrunk here with --configs-small)
+    h = d["with_scalar_h2d"]
+    for k in ("pageable", "pinned"):
+        assert h[k]["verified"] is True and h[k]["ms_per_step"] > 0 and h[k]["value"] > 0
+    assert h["value"] == h["pinned"]["value"] and h["value"] < d["value"] * 1.5
+    cf = d["configs"]
+    assert cf["cfg1"]["n"] == 64 and cf["cfg1"]["proof_bit_exact_vs_oracle"] is True and cf["cfg1"]["create_ms"] > 0 and cf["cfg1"]["verify_ms"] > 0
+    c3 = cf["cfg3_e2e"]
+    assert c3["bytes_equal_oracle"] is True and c3["accepted"] is True and c3["tampered_rejected"] is True and c3["gates"] == 256
+    assert c3["prove_ms"] > 0 and c3["verify_ms"] > 0 and c3["with_precomputed_generator_tables"]["same_proof_bytes"] is True
+    c5 = cf["cfg5"]
+    assert c5["msm_verified"] is True and c5["proof_bit_exact_vs_oracle"] is True and c5["msm_ms"] > 0 and c5["ipp_create_ms"] > 0 and c5["ipp_verify_ms"] > 0
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lg-n", "14", "--steps", "2", "--warmup", "1", "--extras",
                         "--strong-lg", "16", "--rehearse-one-device"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -31,8 +31,9 @@ def synth():
         t.commit_scalar(c, b"s", 5)
         ch = t.challenge_scalar(c, b"c")
         lines.append({"item": "transcript", "curve": cname, "challenge": ch.to_bytes(32, "little").hex(), "after": t.challenge_bytes(b"after", 32).hex()})
-        w = next(x for x in gold("ipp")[cname] if x["name"] == "test_ipp_n4_hashed_generators")
-        lines.append({"item": "ipp", "curve": cname, "name": w["name"], **{k: w[k] for k in ("L", "R", "L_amcl", "a_out", "b_out", "transcript_after")}})
+        for nm in ("test_ipp_n4_hashed_generators", "pin9_n64_hashed_generators"):
+            w = next(x for x in gold("ipp")[cname] if x["name"] == nm)
+            lines.append({"item": "ipp", "curve": cname, "name": w["name"], **{k: w[k] for k in ("L", "R", "L_amcl", "a_out", "b_out", "transcript_after")}})
     return lines
 
 
@@ -51,3 +52,26 @@ def test_compare_pins_accepts_own_assumptions_and_flags_a_difference(tmp_path):
     p = run(lines, tmp_path, "bad.jsonl")
     assert p.returncode == 1 and p.stdout.count("MISMATCH") == 2, p.stdout + p.stderr
     assert os.path.exists(os.path.join(ROOT, "integration", "rust", "pin_fixtures.rs"))
+
+
+def test_pin_kit_uses_only_the_public_api_of_the_reference_and_prints_every_item():
+    """the kit imported bp::transcript (a PRIVATE module, /root/reference src/lib.rs:23), so `cargo test --test
+    pin_fixtures` could not compile; and pin_8 shipped with a placeholder instead of the y_inv constant.  No rustc here: the file is
+    checked as text -- no private path, no placeholder, the constants are the fixtures', every item compare_pins.py knows is printed."""
+    import re
+    src = open(os.path.join(ROOT, "integration", "rust", "pin_fixtures.rs")).read()
+    code = "\n".join(ln for ln in src.splitlines() if not ln.lstrip().startswith("//"))
+    assert "bp::transcript" not in code and "TranscriptProtocol" not in code
+    assert "PASTE" not in src
+    for mod in re.findall(r"use bp::(\w+)", code):
+        assert mod in ("ipp", "utils", "r1cs", "errors"), mod             # the `pub mod`s of src/lib.rs
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ipp.json")))
+    for cname in ("bls12_381", "bn254"):
+        for nm in ("test_ipp_n4_hashed_generators", "pin9_n64_hashed_generators"):
+            case = next(x for x in gold[cname] if x["name"] == nm)
+            assert case["H_factors"][1] in src and nm in src
+            assert case["n"] == len(case["a"]) and [int(x, 16) if False else int.from_bytes(bytes.fromhex(x), "little") for x in case["a"]] == list(range(1, case["n"] + 1))
+    cmp_src = open(os.path.join(ROOT, "scripts", "compare_pins.py")).read()
+    items = set(re.findall(r'item == "(\w+)"', cmp_src))
+    printed = set(re.findall(r'\\"item\\": \\"(\w+)\\"', src))
+    assert items == printed, (items, printed)
