@@ -105,6 +105,12 @@ SYMBOLS = {
     "bp_msm_record_bytes": (_SZ, [_I]),
     "bp_msm_g1_windows": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _P]),
     "bp_msm_g1_finish": (_I, [_P, _P, _SZ, _SZ, _U8P]),
+    "bp_msm_window_records_subset": (_SZ, [_P, _SZ, _I, _I]),
+    "bp_msm_g1_windows_subset": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _I, _I, _SZ, _P]),
+    "bp_msm_g1_finish_blocks": (_I, [_P, _P, _SZ, _SZ, _SZ, _U8P]),
+    "bp_msm_g1_finish_blocks_host": (_I, [_I, _U8P, _SZ, _SZ, _SZ, _I, _U8P]),
+    "bp_msm_record_positions_subset": (_I, [_I, _SZ, _I, _I, _I, ctypes.POINTER(ctypes.c_int), _P]),
+    "bp_msm_record_header_subset": (_I, [_I, _SZ, _I, _I, _I, _P]),
     "bp_msm_g1_finish_host": (_I, [_I, _U8P, _SZ, _SZ, _I, _U8P]),
     "bp_msm_geometry": (_I, [_I, _SZ, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _P, _P, _U8P]),
     "bp_msm_record_from_affine": (_I, [_I, _U8P, _P]),
@@ -483,6 +489,41 @@ def msm_windows(ctx, points, poff, scalars, soff, n, device_out_ptr):
 def msm_finish(ctx, device_records_ptr, sets, n_per_set):
     out = ctypes.create_string_buffer(ctx.point_bytes)
     _check(lib().bp_msm_g1_finish(ctx.h, ctypes.c_void_p(device_records_ptr), sets, n_per_set, out), "bp_msm_g1_finish")
+    return out.raw
+
+
+def msm_window_records_subset(ctx, n, w_first, w_count):
+    """records of the block of one WINDOW GROUP (tail records + header) -- the 2-D sharding of include/bpmsm.h"""
+    return lib().bp_msm_window_records_subset(ctx.h, n, w_first, w_count)
+
+
+def msm_windows_subset(ctx, points, poff, scalars, soff, n, w_first, w_count, block_records, device_out_ptr):
+    _check(lib().bp_msm_g1_windows_subset(ctx.h, points.h, poff, scalars.h, soff, n, w_first, w_count, block_records, ctypes.c_void_p(device_out_ptr)),
+           "bp_msm_g1_windows_subset")
+
+
+def msm_finish_blocks(ctx, device_records_ptr, n_blocks, block_records, n_per_set):
+    out = ctypes.create_string_buffer(ctx.point_bytes)
+    _check(lib().bp_msm_g1_finish_blocks(ctx.h, ctypes.c_void_p(device_records_ptr), n_blocks, block_records, n_per_set, out), "bp_msm_g1_finish_blocks")
+    return out.raw
+
+
+def msm_finish_blocks_host(curve, host_records, n_blocks, block_records, n_per_set, window_bits=0):
+    out = ctypes.create_string_buffer(2 * (48 if curve == BLS12_381 else 32))
+    _check(lib().bp_msm_g1_finish_blocks_host(curve, bytes(host_records), n_blocks, block_records, n_per_set, window_bits, out), "bp_msm_g1_finish_blocks_host")
+    return out.raw
+
+
+def msm_record_positions_subset(curve, n, window_bits, w_first, w_count):
+    nrec = ctypes.c_int()
+    pos = (ctypes.c_uint16 * 4096)()
+    _check(lib().bp_msm_record_positions_subset(curve, n, window_bits, w_first, w_count, ctypes.byref(nrec), ctypes.cast(pos, ctypes.c_void_p)), "bp_msm_record_positions_subset")
+    return [pos[i] for i in range(nrec.value)]
+
+
+def msm_record_header_subset(curve, n, window_bits, w_first, w_count):
+    out = ctypes.create_string_buffer(lib().bp_msm_record_bytes(curve))
+    _check(lib().bp_msm_record_header_subset(curve, n, window_bits, w_first, w_count, out), "bp_msm_record_header_subset")
     return out.raw
 
 

@@ -20,6 +20,10 @@ struct MsmGeom {
     // tail records handed to the host: record r carries weight 2^rpos[r] (bp_host_tail.hpp folds any such list)
     int nrec;
     uint16_t rpos[kMaxRecords];
+    // window SUBSET (bp_msm_g1_windows_subset: shards that split the windows as well as the index range): tab then holds windows
+    // [sub_first, sub_first + sub_count) of the W_full windows of the scalar -- same recoding, same bit offsets -- renumbered from 0
+    int sub_first, sub_count, W_full;
+    uint8_t cw_first_full, cw_last_full, n_wide_full;
 };
 
 static int ilog2(uint32_t v) { int l = 0; while ((1u << (l + 1)) <= v) l++; return l; }
@@ -164,6 +168,31 @@ static int msm_geom(MsmGeom& g, int fr_bits, size_t n, int c_override, int nsets
     // count -- 4.44 -> 4.94 / 5.69 / 9.6 ms for 2 / 4 / 8 groups at n = 2^20, profiles/r02_window_groups.txt -- and was removed in
     // round 3; DESIGN.md section 5 keeps the analysis.)
     g.merged = false;
+    g.sub_first = 0; g.sub_count = W; g.W_full = W;
+    g.cw_first_full = t.cw[0]; g.cw_last_full = t.cw[W - 1]; g.n_wide_full = 0;
+    for (int w = 0; w < W; w++) if (t.cw[w] == t.cw[0]) g.n_wide_full++;
+    return geom_reduce(g, t, tn);
+}
+
+// Restrict a (single-set, bucket-pipeline) geometry to the windows [w0, w0 + wn): the kernels run over a table of wn windows whose
+// bit offsets are the originals (k_digits_bin shifts the biased scalar down to the first one), the records carry the original bit
+// positions, so record blocks of different window groups simply add up in the host fold.
+static int geom_subset(MsmGeom& g, int w0, int wn, const bp_tuning* tn) {
+    WinTab& t = g.tab;
+    if (g.small || g.merged || t.nsets != 1 || w0 < 0 || wn <= 0 || w0 + wn > t.W) return BP_ERR_ARG;
+    if (w0 == 0 && wn == t.W) return BP_OK;
+    uint8_t cw[kMaxWindows], fb[kMaxWindows];
+    uint16_t off[kMaxWindows];
+    for (int w = 0; w < wn; w++) { cw[w] = t.cw[w0 + w]; fb[w] = t.fbits[w0 + w]; off[w] = t.off[w0 + w]; }
+    uint32_t nb = 0, rows = 0;
+    for (int w = 0; w < wn; w++) {
+        t.cw[w] = cw[w]; t.fbits[w] = fb[w]; t.off[w] = off[w];
+        t.boff[w] = nb; t.hoff[w] = (uint16_t)rows;
+        nb += 1u << (cw[w] - 1);
+        rows += 1u << (cw[w] - 1 - fb[w]);
+    }
+    t.boff[wn] = nb; t.hoff[wn] = (uint16_t)rows; t.nbuckets = nb; t.W = wn;
+    g.sub_first = w0; g.sub_count = wn;
     return geom_reduce(g, t, tn);
 }
 
@@ -237,8 +266,12 @@ struct Impl {
         const bp_g1table* dm = nullptr;                     // digit multiples for the single-launch small MSM (bp_g1table::digits)
         if (tb && tb->digits) { dm = tb; tb = nullptr; }
         int rc = tb ? msm_geom_table(g, C::Fr::BITS, tb->c, tb->W, sc2 ? 2 : 1, &ctx->tuning)
-                    : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning, dm && dm->n == n ? kSmallDigitMax : kSmallMsmMax);
+                    : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning, ctx->win_count ? 0 : dm && dm->n == n ? kSmallDigitMax : kSmallMsmMax);
         if (rc) return rc;
+        if (ctx->win_count) {                               // a window group of a sharded MSM (bp_msm_g1_windows_subset): always the pipeline's layout
+            if (tb || dm || sc2 || g.small) return BP_ERR_ARG;
+            if ((rc = geom_subset(g, ctx->win_first, ctx->win_count, &ctx->tuning))) return rc;
+        }
         if (tb) { if (tb->n != n || (uint64_t)tb->W * n >= ((uint64_t)1 << 31)) return BP_ERR_ARG; pts = (const AffPacked<C>*)tb->d; }
         const WinTab& tab = g.tab;                          // digit windows: k_digits_bin, k_coarse_scatter
         const WinTab& tabR = g.merged ? g.tabv : g.tab;     // buckets as the later kernels see them
@@ -510,27 +543,31 @@ struct Impl {
     // Record block of the two-stage (sharded) form: W window records followed by ONE header record that names the geometry
     // which produced them, so that bp_msm_g1_finish can refuse sets that do not fit together (ranks whose shard sizes straddle
     // a power of two pick different window widths unless the caller fixes c with bp_ctx_set_window_bits).
-    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, nrec, m, small; };   // widths: n_wide windows of cw_first bits, then cw_last
+    struct RecHeader { uint32_t magic, c, W, fr_bits, cw_first, cw_last, n_wide, nrec, m, small, w0, wn; };   // widths: n_wide windows of cw_first bits, then cw_last; w0, wn: the window group
     static_assert(sizeof(RecHeader) <= sizeof(XyzzPacked<C>), "header must fit one record");
-    static constexpr uint32_t kRecMagic = 0x32575042u;   // "BPW2" (round 3: bit-plane records; a round-2 block "BPW1" is refused)
+    static constexpr uint32_t kRecMagic = 0x33575042u;   // "BPW3" (round 4: + the window group; blocks of rounds 2 / 3 -- "BPW1" / "BPW2" -- are refused)
     static void fill_header(RecHeader& h, const MsmGeom& g) {
         memset(&h, 0, sizeof h);
-        h.magic = kRecMagic; h.c = (uint32_t)g.c; h.W = (uint32_t)g.tab.W; h.fr_bits = (uint32_t)C::Fr::BITS;
-        h.cw_first = g.tab.cw[0]; h.cw_last = g.tab.cw[g.tab.W - 1];
-        for (int w = 0; w < g.tab.W; w++) if (g.tab.cw[w] == g.tab.cw[0]) h.n_wide++;
+        h.magic = kRecMagic; h.c = (uint32_t)g.c; h.W = (uint32_t)g.W_full; h.fr_bits = (uint32_t)C::Fr::BITS;
+        h.cw_first = g.cw_first_full; h.cw_last = g.cw_last_full; h.n_wide = g.n_wide_full;
         h.nrec = (uint32_t)g.nrec; h.m = g.m; h.small = g.small ? (uint32_t)g.small_blocks : 0u;
+        h.w0 = (uint32_t)g.sub_first; h.wn = (uint32_t)g.sub_count;
     }
 
-    static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out) {
+    // block_records (window groups only): the header goes to the LAST record of a block of that many (groups differ in record count)
+    static int msm_windows_to(bp_ctx* ctx, const void* pts, size_t poff, const void* sc, size_t soff, size_t n, void* device_out, size_t block_records = 0) {
         MsmGeom g;
         int rc = msm_windows(ctx, (const AffPacked<C>*)pts + poff, (const ScalarWords*)sc + soff, n, g);
         if (rc) return rc;
         const int W = g.nrec;
+        if (block_records && block_records < (size_t)W + 1) return BP_ERR_ARG;
+        const size_t hdr_at = block_records ? block_records - 1 : (size_t)W;
         HIPCHK(hipMemcpyAsync(device_out, ctx->window_sum.p, (size_t)W * kXyzzBytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (hdr_at > (size_t)W) HIPCHK(hipMemsetAsync((uint8_t*)device_out + (size_t)W * kXyzzBytes, 0, (hdr_at - W) * kXyzzBytes, ctx->stream));
         if ((rc = host_pinned_reserve(ctx, kXyzzBytes))) return rc;
         memset(ctx->host_pinned, 0, kXyzzBytes);
         fill_header(*(RecHeader*)ctx->host_pinned, g);
-        HIPCHK(hipMemcpyAsync((uint8_t*)device_out + (size_t)W * kXyzzBytes, ctx->host_pinned, kXyzzBytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync((uint8_t*)device_out + hdr_at * kXyzzBytes, ctx->host_pinned, kXyzzBytes, hipMemcpyHostToDevice, ctx->stream));
         // The records are about to be read by another stream (RCCL's) or another device: complete them before returning.
         HIPCHK(hipStreamSynchronize(ctx->stream));
         collect_timing(ctx);
@@ -552,6 +589,37 @@ struct Impl {
             memcpy(&packed[s * (size_t)W], set, (size_t)W * kXyzzBytes);
         }
         fold1(ctx, packed.data(), sets, W, g.rpos, out_le);
+        return BP_OK;
+    }
+
+    // Blocks of `stride` records each, the LAST one the header, records [0, header.nrec) valid (the rest padding): shards of a 2-D split
+    // (index range x window group) have different record counts per block.  Every header must name the caller's full geometry; its
+    // window group gives the block's bit positions.  One fold over all records.
+    static int finish_blocks_host(int c_override, const XyzzPacked<C>* host_rec, size_t nblocks, size_t stride, size_t n_per_set, uint8_t* out_le,
+                                  const bp_tuning* tn = nullptr, bp_ctx* ctx = nullptr) {
+        if (stride < 2) return BP_ERR_ARG;
+        MsmGeom full;
+        if (msm_geom(full, C::Fr::BITS, n_per_set, c_override, 1, 0, tn, 0)) return BP_ERR_ARG;
+        std::vector<XyzzPacked<C>> packed;
+        std::vector<uint16_t> pos;
+        uint32_t cover[kMaxWindows] = {0};             // how many blocks hold window w: equal for all w, or the groups do not tile the windows
+        for (size_t b = 0; b < nblocks; b++) {
+            const XyzzPacked<C>* blk = host_rec + b * stride;
+            RecHeader h;
+            memcpy(&h, &blk[stride - 1], sizeof h);
+            MsmGeom g = full;
+            if (h.w0 >= (uint32_t)full.tab.W || h.wn == 0 || h.wn > (uint32_t)full.tab.W - h.w0) return BP_ERR_ARG;
+            for (uint32_t w = h.w0; w < h.w0 + h.wn; w++) cover[w]++;
+            if (geom_subset(g, (int)h.w0, (int)h.wn, tn)) return BP_ERR_ARG;
+            RecHeader want;
+            fill_header(want, g);
+            if (memcmp(&h, &want, sizeof want) != 0 || (size_t)g.nrec > stride - 1) return BP_ERR_ARG;
+            packed.insert(packed.end(), blk, blk + g.nrec);
+            pos.insert(pos.end(), g.rpos, g.rpos + g.nrec);
+        }
+        for (int w = 1; w < full.tab.W; w++) if (cover[w] != cover[0]) return BP_ERR_ARG;
+        if (packed.size() > (size_t)kMaxRecords) return BP_ERR_ARG;
+        fold1(ctx, packed.data(), 1, (int)packed.size(), pos.data(), out_le);
         return BP_OK;
     }
 
@@ -838,12 +906,15 @@ extern "C" {
 const char* bp_version(void) { return "bpmsm 0.1 (gfx950; unsaturated 30-bit limbs; Pippenger/XYZZ)"; }
 
 int bp_device_count(void) {
+    return bp_guard([&]() -> int {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+    });
 }
 
 int bp_curve_params(int curve_id, bp_curve_info* out) {
+    return bp_guard([&]() -> int {
     if (!out || !curve_ok(curve_id)) return BP_ERR_ARG;
     memset(out, 0, sizeof *out);
     out->curve_id = curve_id;
@@ -858,9 +929,11 @@ int bp_curve_params(int curve_id, bp_curve_info* out) {
         memcpy(out->gen_le, Bn254::GX, 32); memcpy(out->gen_le + 32, Bn254::GY, 32);
     }
     return BP_OK;
+    });
 }
 
 int bp_ctx_create(int curve_id, int device_ordinal, bp_ctx** out) {
+    return bp_guard([&]() -> int {
     if (!out || !curve_ok(curve_id)) return BP_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -878,9 +951,11 @@ int bp_ctx_create(int curve_id, int device_ordinal, bp_ctx** out) {
     ctx->pool->device = device_ordinal;
     *out = ctx;
     return BP_OK;
+    });
 }
 
 int bp_ctx_destroy(bp_ctx* ctx) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_OK;
     for (auto& h : ctx->helper) { if (h) bp_ctx_destroy(h); h = nullptr; }
     (void)hipSetDevice(ctx->device);
@@ -895,6 +970,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return BP_OK;
+    });
 }
 
 // Sibling context k of `ctx` (same curve, device and options; its own stream and workspace), created on first use and destroyed
@@ -914,13 +990,16 @@ bp_ctx* bp_internal_helper(bp_ctx* ctx, int k) {
     return h;
 }
 int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling) {
+    return bp_guard([&]() -> int {
     if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(sibling->stream, ctx->ev_fork, 0));
     return BP_OK;
+    });
 }
 
 int bp_ctx_set_stream(bp_ctx* ctx, void* hip_stream) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_ERR_ARG;
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     if (next != ctx->stream) {   // pool blocks are recycled in stream order: drain the old stream before work moves to another
@@ -929,22 +1008,28 @@ int bp_ctx_set_stream(bp_ctx* ctx, void* hip_stream) {
     }
     ctx->stream = next;
     return BP_OK;
+    });
 }
 
 int bp_ctx_synchronize(bp_ctx* ctx) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BP_OK;
+    });
 }
 
 int bp_ctx_set_window_bits(bp_ctx* ctx, int c) {
+    return bp_guard([&]() -> int {
     if (!ctx || c < 0 || c > 16 || c == 1) return BP_ERR_ARG;
     ctx->c_override = c;
     return BP_OK;
+    });
 }
 
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
+    return bp_guard([&]() -> int {
     if (!ctx || value < 0) return BP_ERR_ARG;
     switch (knob) {
     case BP_TUNE_TILE:          // k_digits_bin / k_coarse_scatter give every lane tile / 256 scalars: anything else would skip scalars
@@ -974,31 +1059,39 @@ int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
     default:
         return BP_ERR_ARG;
     }
+    });
 }
 
 int bp_ctx_set_device_tail(bp_ctx* ctx, int on) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_ERR_ARG;
     ctx->device_tail = on != 0;
     return BP_OK;
+    });
 }
 
 int bp_ctx_enable_timing(bp_ctx* ctx, int on) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_ERR_ARG;
     ctx->timing = on != 0;
     return BP_OK;
+    });
 }
 
 int bp_msm_last_timing(bp_ctx* ctx, float* ms, int cap) {
+    return bp_guard([&]() -> int {
     if (!ctx || !ms) return 0;
     int k = ctx->last_ms_n < cap ? ctx->last_ms_n : cap;
     for (int i = 0; i < k; i++) ms[i] = ctx->last_ms[i];
     return k;
+    });
 }
 
 // ---- G1Vector ----
 static size_t point_bytes(const bp_ctx* ctx) { return 2 * (size_t)fp_bytes_of(ctx->curve); }
 
 int bp_g1vec_alloc(bp_ctx* ctx, size_t n, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out) return BP_ERR_ARG;
     *out = nullptr;
     int rc = set_device(ctx); if (rc) return rc;
@@ -1008,9 +1101,11 @@ int bp_g1vec_alloc(bp_ctx* ctx, size_t n, bp_g1vec** out) {
     if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { ctx->pool->put(d, cap); return BP_ERR_DEVICE; }
     *out = new bp_g1vec{ctx, d, n, true, ctx->device, ctx->pool, cap};
     return BP_OK;
+    });
 }
 
 int bp_g1vec_upload(bp_ctx* ctx, const uint8_t* points, size_t n, int fmt, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (!points && n) || (fmt != BP_FMT_LE && fmt != BP_FMT_AMCL)) return BP_ERR_ARG;
     int rc = bp_g1vec_alloc(ctx, n, out);
     if (rc) return rc;
@@ -1035,9 +1130,11 @@ int bp_g1vec_upload(bp_ctx* ctx, const uint8_t* points, size_t n, int fmt, bp_g1
     else rc = Impl<Bn254>::upload_points(ctx, src, n, (*out)->d, true);
     if (rc) { bp_g1vec_free(*out); *out = nullptr; }
     return rc;
+    });
 }
 
 int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, int fmt, uint8_t* out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !v || (!out && n) || (fmt != BP_FMT_LE && fmt != BP_FMT_AMCL)) return BP_ERR_ARG;
     if (offset > v->n || n > v->n - offset) return BP_ERR_LENGTH;
     if (n == 0) return BP_OK;
@@ -1062,6 +1159,7 @@ int bp_g1vec_download(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, i
         }
     }
     return BP_OK;
+    });
 }
 
 void bp_internal_table_free(bp_g1table* t) {
@@ -1084,15 +1182,18 @@ static void recycle_block(DevPool* pool, int device, void* d, size_t cap, bool e
 }
 
 int bp_g1vec_free(bp_g1vec* v) {
+    return bp_guard([&]() -> int {
     if (!v) return BP_OK;
     if (v->table) bp_internal_table_free(v->table);
     if (v->ctable) bp_internal_table_free(v->ctable);
     if (v->owned && v->d) recycle_block(v->pool, v->device, v->d, v->cap, v->exported);
     delete v;
     return BP_OK;
+    });
 }
 
 int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits) {
+    return bp_guard([&]() -> int {
     if (!ctx || !v || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     if (v->n == 0) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
@@ -1115,16 +1216,20 @@ int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits) {
         if (v->ctable) { bp_internal_table_free(v->ctable); v->ctable = nullptr; }
     }
     return rc;
+    });
 }
 
 int bp_g1vec_drop_table(bp_g1vec* v) {
+    return bp_guard([&]() -> int {
     if (!v) return BP_ERR_ARG;
     if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
     if (v->ctable) { bp_internal_table_free(v->ctable); v->ctable = nullptr; }
     return BP_OK;
+    });
 }
 
 int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_t* bytes) {
+    return bp_guard([&]() -> int {
     if (!v) return BP_ERR_ARG;
     const bp_g1table* t = v->table;
     if (window_bits) *window_bits = t ? t->c : 0;
@@ -1132,18 +1237,22 @@ int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_
     if (bytes) *bytes = (t ? (size_t)t->W * t->n : 0) * 2 * (size_t)fp_bytes_of(v->ctx->curve) +
                         (v->ctable ? (size_t)v->ctable->W * v->ctable->K * v->ctable->n * 2 * (size_t)fp_bytes_of(v->ctx->curve) : 0);   // + the compaction table
     return BP_OK;
+    });
 }
 
 size_t bp_g1vec_len(const bp_g1vec* v) { return v ? v->n : 0; }
 void* bp_g1vec_device_ptr(bp_g1vec* v) { if (!v) return nullptr; v->exported = true; return v->d; }
 
 int bp_g1vec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
     *out = new bp_g1vec{ctx, device_ptr, n, false, ctx->device, nullptr, 0};
     return BP_OK;
+    });
 }
 
 int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !k || !out) return BP_ERR_ARG;
     if (p && p->n != k->n) return BP_ERR_LENGTH;
     int rc = bp_g1vec_alloc(ctx, k->n, out);
@@ -1156,12 +1265,14 @@ int bp_g1vec_scalar_mul(bp_ctx* ctx, const bp_g1vec* p, const bp_frvec* k, bp_g1
     else rc = Impl<Bn254>::scalar_mul(ctx, p->d, k->d, k->n, (*out)->d);
     if (rc) { bp_g1vec_free(*out); *out = nullptr; }
     return rc;
+    });
 }
 
 int bp_g1vec_fixed_base_mul(bp_ctx* ctx, const bp_frvec* k, bp_g1vec** out) { return bp_g1vec_scalar_mul(ctx, nullptr, k, out); }
 
 // ---- FieldElementVector ----
 int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out) return BP_ERR_ARG;
     *out = nullptr;
     int rc = set_device(ctx); if (rc) return rc;
@@ -1171,9 +1282,11 @@ int bp_frvec_alloc(bp_ctx* ctx, size_t n, bp_frvec** out) {
     if (hipMemsetAsync(d, 0, bytes, ctx->stream) != hipSuccess) { ctx->pool->put(d, cap); return BP_ERR_DEVICE; }
     *out = new bp_frvec{ctx, d, n, true, ctx->device, ctx->pool, cap};
     return BP_OK;
+    });
 }
 
 int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (!scalars_le32 && n)) return BP_ERR_ARG;
     int rc = bp_frvec_alloc(ctx, n, out);
     if (rc) return rc;
@@ -1186,9 +1299,11 @@ int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec
     rc = ctx->curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::check_scalars(ctx, (*out)->d, n) : Impl<Bn254>::check_scalars(ctx, (*out)->d, n);
     if (rc) { bp_frvec_free(*out); *out = nullptr; }
     return rc;
+    });
 }
 
 int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, uint8_t* out_le32) {
+    return bp_guard([&]() -> int {
     if (!ctx || !v || (!out_le32 && n)) return BP_ERR_ARG;
     if (offset > v->n || n > v->n - offset) return BP_ERR_LENGTH;
     if (n == 0) return BP_OK;
@@ -1196,67 +1311,84 @@ int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, u
     HIPCHK(hipMemcpyAsync(out_le32, (const uint8_t*)v->d + offset * 32, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BP_OK;
+    });
 }
 
 int bp_frvec_copy(bp_ctx* ctx, bp_frvec* dst, size_t dst_off, const bp_frvec* src, size_t src_off, size_t n) {
+    return bp_guard([&]() -> int {
     if (!ctx || !dst || !src) return BP_ERR_ARG;
     if (dst_off > dst->n || n > dst->n - dst_off || src_off > src->n || n > src->n - src_off) return BP_ERR_LENGTH;
     if (n == 0) return BP_OK;
     int rc = set_device(ctx); if (rc) return rc;
     HIPCHK(hipMemcpyAsync((uint8_t*)dst->d + dst_off * 32, (const uint8_t*)src->d + src_off * 32, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
     return BP_OK;
+    });
 }
 
 int bp_frvec_free(bp_frvec* v) {
+    return bp_guard([&]() -> int {
     if (!v) return BP_OK;
     if (v->owned && v->d) recycle_block(v->pool, v->device, v->d, v->cap, v->exported);
     delete v;
     return BP_OK;
+    });
 }
 
 size_t bp_frvec_len(const bp_frvec* v) { return v ? v->n : 0; }
 void* bp_frvec_device_ptr(bp_frvec* v) { if (!v) return nullptr; v->exported = true; return v->d; }
 
 int bp_frvec_wrap_device(bp_ctx* ctx, void* device_ptr, size_t n, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (!device_ptr && n) || ((uintptr_t)device_ptr & 15)) return BP_ERR_ARG;
     *out = new bp_frvec{ctx, device_ptr, n, false, ctx->device, nullptr, 0};
     return BP_OK;
+    });
 }
 
 // ---- MSM ----
 int bp_msm_g1_range(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
     if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
     if (poff > points->n || n > points->n - poff || soff > scalars->n || n > scalars->n - soff) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
     const bp_g1table* tb = (points->table && poff == 0 && n == points->n && points->table->n == n) ? points->table : nullptr;
     DISPATCH(ctx, I::msm(ctx, points->d, poff, scalars->d, soff, n, out_le, tb));
+    });
 }
 
 int bp_msm_g1(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
     if (!ctx || !points || !scalars || !out_le) return BP_ERR_ARG;
     if (points->n != scalars->n) return BP_ERR_LENGTH;
     return bp_msm_g1_range(ctx, points, 0, scalars, 0, points->n, out_le);
+    });
 }
 
 int bp_msm_g1_begin(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars) {
+    return bp_guard([&]() -> int {
     if (!ctx || !points || !scalars) return BP_ERR_ARG;
     if (points->n != scalars->n) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
     const bp_g1table* tb = points->table && points->table->n == points->n ? points->table : nullptr;
     DISPATCH(ctx, I::msm_begin(ctx, points->d, 0, scalars->d, 0, points->n, tb));
+    });
 }
 
 int bp_msm_g1_end(bp_ctx* ctx, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out_le) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
     DISPATCH(ctx, I::msm_end(ctx, out_le));
+    });
 }
 
 int bp_msm_g1_pair(bp_ctx* ctx, const bp_g1vec* points, const bp_frvec* scalars1, const bp_frvec* scalars2, uint8_t* out1_le, uint8_t* out2_le) {
+    return bp_guard([&]() -> int {
     if (!ctx || !points || !scalars1 || !scalars2 || !out1_le || !out2_le) return BP_ERR_ARG;
     if (points->n != scalars1->n || points->n != scalars2->n) return BP_ERR_LENGTH;
     int rc = set_device(ctx); if (rc) return rc;
     return bp_internal_msm2(ctx, points->d, scalars1->d, scalars2->d, points->n, out1_le, out2_le, 0, points->table && points->table->n == points->n ? points->table : nullptr);
+    });
 }
 
 size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {
@@ -1270,25 +1402,107 @@ size_t bp_msm_window_records(bp_ctx* ctx, size_t n) {
 size_t bp_msm_record_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? sizeof(XyzzPacked<Bls381>) : sizeof(XyzzPacked<Bn254>); }
 
 int bp_msm_g1_windows(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n, void* device_out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !points || !scalars || !device_out || n == 0) return BP_ERR_ARG;
     if (poff > points->n || n > points->n - poff || soff > scalars->n || n > scalars->n - soff) return BP_ERR_LENGTH;
+    // the context-free helpers a receiving host uses (bp_msm_record_positions / _geometry / _record_header / _finish_host) know the
+    // DEFAULT record layout only: a context tuned to another one must not hand out record blocks
+    if (ctx->tuning.reduce_m != 0 || !ctx->tuning.small_msm) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
     DISPATCH(ctx, I::msm_windows_to(ctx, points->d, poff, scalars->d, soff, n, device_out));
+    });
+}
+
+// ---- 2-D sharding: index range x window group ----------------------------------------------------------------
+size_t bp_msm_window_records_subset(bp_ctx* ctx, size_t n, int w_first, int w_count) {
+    if (!ctx || n == 0) return 0;
+    MsmGeom g;
+    const int bits = ctx->curve == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
+    if (msm_geom(g, bits, n, ctx->c_override, 1, 0, &ctx->tuning, 0)) return 0;
+    if (geom_subset(g, w_first, w_count, &ctx->tuning)) return 0;
+    return (size_t)g.nrec + 1;
+}
+
+int bp_msm_g1_windows_subset(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n, int w_first, int w_count,
+                             size_t block_records, void* device_out) {
+    return bp_guard([&]() -> int {
+    if (!ctx || !points || !scalars || !device_out || n == 0 || w_first < 0 || w_count <= 0 || block_records < 2) return BP_ERR_ARG;
+    if (poff > points->n || n > points->n - poff || soff > scalars->n || n > scalars->n - soff) return BP_ERR_LENGTH;
+    int rc = set_device(ctx); if (rc) return rc;
+    ctx->win_first = w_first; ctx->win_count = w_count;
+    rc = ctx->curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::msm_windows_to(ctx, points->d, poff, scalars->d, soff, n, device_out, block_records)
+                                          : Impl<Bn254>::msm_windows_to(ctx, points->d, poff, scalars->d, soff, n, device_out, block_records);
+    ctx->win_first = 0; ctx->win_count = 0;
+    return rc;
+    });
+}
+
+int bp_msm_g1_finish_blocks(bp_ctx* ctx, const void* device_records, size_t n_blocks, size_t block_records, size_t n_per_set, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
+    if (!ctx || !device_records || !out_le || n_blocks == 0 || block_records < 2 || n_per_set == 0) return BP_ERR_ARG;
+    int rc = set_device(ctx); if (rc) return rc;
+    const size_t bytes = n_blocks * block_records * bp_msm_record_bytes(ctx->curve);
+    if ((rc = host_pinned_reserve(ctx, bytes))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->host_pinned, device_records, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        return Impl<Bls381>::finish_blocks_host(ctx->c_override, (const XyzzPacked<Bls381>*)ctx->host_pinned, n_blocks, block_records, n_per_set, out_le, &ctx->tuning, ctx);
+    return Impl<Bn254>::finish_blocks_host(ctx->c_override, (const XyzzPacked<Bn254>*)ctx->host_pinned, n_blocks, block_records, n_per_set, out_le, &ctx->tuning, ctx);
+    });
+}
+
+int bp_msm_g1_finish_blocks_host(int curve_id, const void* host_records, size_t n_blocks, size_t block_records, size_t n_per_set, int window_bits, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
+    if (!curve_ok(curve_id) || !host_records || !out_le || n_blocks == 0 || block_records < 2 || n_per_set == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1)
+        return BP_ERR_ARG;
+    if (curve_id == BP_CURVE_BLS12_381) return Impl<Bls381>::finish_blocks_host(window_bits, (const XyzzPacked<Bls381>*)host_records, n_blocks, block_records, n_per_set, out_le);
+    return Impl<Bn254>::finish_blocks_host(window_bits, (const XyzzPacked<Bn254>*)host_records, n_blocks, block_records, n_per_set, out_le);
+    });
+}
+
+// context-free forms for a host that only receives blocks (default tuning): bit positions and header of one window group's block
+int bp_msm_record_positions_subset(int curve_id, size_t n, int window_bits, int w_first, int w_count, int* nrec_out, uint16_t* pos_out) {
+    return bp_guard([&]() -> int {
+    if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    MsmGeom g;
+    if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits, 1, 0, nullptr, 0)) return BP_ERR_ARG;
+    if (geom_subset(g, w_first, w_count, nullptr)) return BP_ERR_ARG;
+    if (nrec_out) *nrec_out = g.nrec;
+    if (pos_out) for (int r = 0; r < g.nrec; r++) pos_out[r] = g.rpos[r];
+    return BP_OK;
+    });
+}
+int bp_msm_record_header_subset(int curve_id, size_t n, int window_bits, int w_first, int w_count, void* record_out) {
+    return bp_guard([&]() -> int {
+    if (!curve_ok(curve_id) || !record_out || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
+    MsmGeom g;
+    if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits, 1, 0, nullptr, 0)) return BP_ERR_ARG;
+    if (geom_subset(g, w_first, w_count, nullptr)) return BP_ERR_ARG;
+    memset(record_out, 0, bp_msm_record_bytes(curve_id));
+    if (curve_id == BP_CURVE_BLS12_381) Impl<Bls381>::fill_header(*(Impl<Bls381>::RecHeader*)record_out, g);
+    else Impl<Bn254>::fill_header(*(Impl<Bn254>::RecHeader*)record_out, g);
+    return BP_OK;
+    });
 }
 
 int bp_msm_g1_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
     if (!ctx || !device_records || !out_le || sets == 0 || n_per_set == 0) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
     DISPATCH(ctx, I::msm_finish(ctx, device_records, sets, n_per_set, out_le));
+    });
 }
 
 int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, size_t n_per_set, int window_bits, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || !host_records || !out_le || sets == 0 || n_per_set == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) return Impl<Bls381>::finish_host(window_bits, (const XyzzPacked<Bls381>*)host_records, sets, n_per_set, out_le);
     return Impl<Bn254>::finish_host(window_bits, (const XyzzPacked<Bn254>*)host_records, sets, n_per_set, out_le);
+    });
 }
 
 int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_out, uint8_t* cw_out, uint16_t* off_out, uint8_t* bias_le32) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     MsmGeom g;
     if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits)) return BP_ERR_ARG;
@@ -1297,25 +1511,31 @@ int bp_msm_geometry(int curve_id, size_t n, int window_bits, int* c_out, int* W_
     for (int w = 0; w < g.tab.W; w++) { if (cw_out) cw_out[w] = g.tab.cw[w]; if (off_out) off_out[w] = g.tab.off[w]; }
     if (bias_le32) memcpy(bias_le32, g.tab.bias.w, 32);
     return BP_OK;
+    });
 }
 
 int bp_msm_record_positions(int curve_id, size_t n, int window_bits, int* nrec_out, uint16_t* pos_out) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     MsmGeom g;
     if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits)) return BP_ERR_ARG;
     if (nrec_out) *nrec_out = g.nrec;
     if (pos_out) for (int r = 0; r < g.nrec; r++) pos_out[r] = g.rpos[r];
     return BP_OK;
+    });
 }
 
 int bp_msm_record_from_affine(int curve_id, const uint8_t* point_le, void* record_out) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || !point_le || !record_out) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) Impl<Bls381>::record_from_affine(point_le, (XyzzPacked<Bls381>*)record_out);
     else Impl<Bn254>::record_from_affine(point_le, (XyzzPacked<Bn254>*)record_out);
     return BP_OK;
+    });
 }
 
 int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_out) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || !record_out || n == 0 || window_bits < 0 || window_bits > 16 || window_bits == 1) return BP_ERR_ARG;
     MsmGeom g;
     if (msm_geom(g, curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS, n, window_bits)) return BP_ERR_ARG;
@@ -1323,6 +1543,7 @@ int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_o
     if (curve_id == BP_CURVE_BLS12_381) Impl<Bls381>::fill_header(*(Impl<Bls381>::RecHeader*)record_out, g);
     else Impl<Bn254>::fill_header(*(Impl<Bn254>::RecHeader*)record_out, g);
     return BP_OK;
+    });
 }
 
 // One host thread, several devices (or several contexts on one device), no RCCL: shard i = (points[i], scalars[i]) lives with
@@ -1330,6 +1551,7 @@ int bp_msm_record_header(int curve_id, size_t n, int window_bits, void* record_o
 // window width so that the records fit together; each device copies its W window sums (W x 192 B) to pinned host memory and
 // the calling thread folds the N record sets.  The "reduce" of north_star is this gather: N x 3 KiB, latency-bound.
 int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp_frvec* const* scalars, size_t n_shards, uint8_t* out_le) {
+    return bp_guard([&]() -> int {
     if (!ctxs || !points || !scalars || !out_le || n_shards == 0 || n_shards > 64) return BP_ERR_ARG;
     size_t n_max = 0;
     for (size_t i = 0; i < n_shards; i++) {
@@ -1387,14 +1609,17 @@ int bp_msm_g1_multi(bp_ctx* const* ctxs, const bp_g1vec* const* points, const bp
         for (size_t i = 0; i < n_shards; i++) if (ctxs[i]) { (void)set_device(ctxs[i]); (void)hipStreamSynchronize(ctxs[i]->stream); }
         return BP_ERR_DEVICE;
     }
+    });
 }
 
 int bp_ctx_trim(bp_ctx* ctx) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_ERR_ARG;
     int rc = set_device(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->pool->trim();
     return BP_OK;
+    });
 }
 
 }  // extern "C"

@@ -105,14 +105,17 @@ extern "C" {
 size_t bp_g1_compressed_bytes(int curve_id) { return curve_id == BP_CURVE_BLS12_381 ? Bls381::MODBYTES + 1 : curve_id == BP_CURVE_BN254 ? Bn254::MODBYTES + 1 : 0; }
 
 int bp_g1vec_compress(bp_ctx* ctx, const bp_g1vec* v, size_t offset, size_t n, uint8_t* out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !v || (!out && n)) return BP_ERR_ARG;
     if (offset > v->n || n > v->n - offset) return BP_ERR_LENGTH;
     if (n == 0) return BP_OK;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     return ctx->curve == BP_CURVE_BLS12_381 ? compress_impl<Bls381>(ctx, v, offset, n, out) : compress_impl<Bn254>(ctx, v, offset, n, out);
+    });
 }
 
 int bp_g1vec_decompress(bp_ctx* ctx, const uint8_t* in, size_t n, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (!in && n)) return BP_ERR_ARG;
     *out = nullptr;
     int rc = bp_g1vec_alloc(ctx, n, out);
@@ -120,6 +123,7 @@ int bp_g1vec_decompress(bp_ctx* ctx, const uint8_t* in, size_t n, bp_g1vec** out
     rc = ctx->curve == BP_CURVE_BLS12_381 ? decompress_impl<Bls381>(ctx, in, n, *out) : decompress_impl<Bn254>(ctx, in, n, *out);
     if (rc) { bp_g1vec_free(*out); *out = nullptr; }
     return rc;
+    });
 }
 
 // R1CS proof <-> its compressed wire form: every point of the layout of bp_r1cs_prove as 1 + MODBYTES bytes, the five scalars
@@ -132,6 +136,7 @@ size_t bp_r1cs_proof_compressed_bytes(int curve_id, size_t n) {
 }
 
 int bp_r1cs_proof_compress(bp_ctx* ctx, size_t n, const uint8_t* proof, size_t proof_len, uint8_t* out, size_t out_cap) {
+    return bp_guard([&]() -> int {
     if (!ctx || !proof || !out || n == 0) return BP_ERR_ARG;
     const size_t pb = 2 * (size_t)fp_bytes_of(ctx->curve), np = r1cs_points(n), cb = bp_g1_compressed_bytes(ctx->curve);
     if (proof_len != np * pb + 5 * 32 || out_cap < np * cb + 5 * 32) return BP_ERR_LENGTH;
@@ -150,9 +155,11 @@ int bp_r1cs_proof_compress(bp_ctx* ctx, size_t n, const uint8_t* proof, size_t p
     memcpy(out + 11 * cb + 96, comp.data() + 11 * cb, (np - 11) * cb);
     memcpy(out + np * cb + 96, proof + np * pb + 96, 64);
     return BP_OK;
+    });
 }
 
 int bp_r1cs_proof_decompress(bp_ctx* ctx, size_t n, const uint8_t* in, size_t in_len, uint8_t* proof_out, size_t proof_cap) {
+    return bp_guard([&]() -> int {
     if (!ctx || !in || !proof_out || n == 0) return BP_ERR_ARG;
     const size_t pb = 2 * (size_t)fp_bytes_of(ctx->curve), np = r1cs_points(n), cb = bp_g1_compressed_bytes(ctx->curve);
     if (in_len != np * cb + 5 * 32 || proof_cap < np * pb + 5 * 32) return BP_ERR_LENGTH;
@@ -170,9 +177,11 @@ int bp_r1cs_proof_decompress(bp_ctx* ctx, size_t n, const uint8_t* in, size_t in
     memcpy(proof_out + 11 * pb + 96, pts.data() + 11 * pb, (np - 11) * pb);
     memcpy(proof_out + np * pb + 96, in + np * cb + 96, 64);
     return BP_OK;
+    });
 }
 
 int bp_g1vec_from_msg_hash(bp_ctx* ctx, const uint8_t* msgs, const uint64_t* offsets, size_t n, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (n && !offsets)) return BP_ERR_ARG;
     *out = nullptr;
     size_t total = 0;
@@ -186,14 +195,17 @@ int bp_g1vec_from_msg_hash(bp_ctx* ctx, const uint8_t* msgs, const uint64_t* off
     }
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     return hash_common(ctx, msgs, total, offsets, 0, n, out);
+    });
 }
 
 int bp_get_generators(bp_ctx* ctx, const uint8_t* prefix, size_t prefix_len, uint64_t first, size_t n, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (prefix_len && !prefix) || prefix_len > 0x7fffffffull) return BP_ERR_ARG;
     *out = nullptr;
     if (n && first + (n - 1) < first) return BP_ERR_ARG;   // the counter must not wrap
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     return hash_common(ctx, prefix, prefix_len, nullptr, first, n, out);
+    });
 }
 
 }  // extern "C"

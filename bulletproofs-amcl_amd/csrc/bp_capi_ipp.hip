@@ -868,62 +868,81 @@ extern "C" {
 
 // ---- transcript ---------------------------------------------------------------------------------------------
 int bp_transcript_new(const uint8_t* label, size_t label_len, bp_transcript** out) {
+    return bp_guard([&]() -> int {
     if (!out || (!label && label_len)) return BP_ERR_ARG;
     *out = new (std::nothrow) bp_transcript(label, label_len);
     return *out ? BP_OK : BP_ERR_DEVICE;
+    });
 }
 int bp_transcript_free(bp_transcript* t) { delete t; return BP_OK; }
 int bp_transcript_append_message(bp_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len) {
+    return bp_guard([&]() -> int {
     if (!t) return BP_ERR_ARG;
     t->t.append_message(label, label_len, msg, msg_len);
     return BP_OK;
+    });
 }
 int bp_transcript_append_u64(bp_transcript* t, const uint8_t* label, size_t label_len, uint64_t x) {
+    return bp_guard([&]() -> int {
     if (!t) return BP_ERR_ARG;
     t->t.append_u64(label, label_len, x);
     return BP_OK;
+    });
 }
 int bp_transcript_challenge_bytes(bp_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len) {
+    return bp_guard([&]() -> int {
     if (!t || (!out && out_len)) return BP_ERR_ARG;
     t->t.challenge_bytes(label, label_len, out, out_len);
     return BP_OK;
+    });
 }
 int bp_transcript_commit_point(bp_transcript* t, int curve_id, const char* label, const uint8_t* point_le) {
+    return bp_guard([&]() -> int {
     if (!t || !curve_ok(curve_id) || !label || !point_le) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_point(t->t, label, point_le); else Ipp<Bn254>::commit_point(t->t, label, point_le);
     return BP_OK;
+    });
 }
 int bp_transcript_commit_points(bp_transcript* t, int curve_id, const char* label, const uint8_t* points_le, size_t n) {
+    return bp_guard([&]() -> int {
     if (!t || !curve_ok(curve_id) || !label || (!points_le && n)) return BP_ERR_ARG;
     const size_t pb = curve_id == BP_CURVE_BLS12_381 ? 2 * 4 * Bls381::Fp::NW : 2 * 4 * Bn254::Fp::NW;
     for (size_t i = 0; i < n; i++) {
         if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_point(t->t, label, points_le + i * pb); else Ipp<Bn254>::commit_point(t->t, label, points_le + i * pb);
     }
     return BP_OK;
+    });
 }
 int bp_transcript_commit_scalar(bp_transcript* t, int curve_id, const char* label, const uint8_t* scalar_le32) {
+    return bp_guard([&]() -> int {
     if (!t || !curve_ok(curve_id) || !label || !scalar_le32) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) Ipp<Bls381>::commit_scalar(t->t, label, scalar_le32); else Ipp<Bn254>::commit_scalar(t->t, label, scalar_le32);
     return BP_OK;
+    });
 }
 int bp_transcript_challenge_scalar(bp_transcript* t, int curve_id, const char* label, uint8_t* out_le32) {
+    return bp_guard([&]() -> int {
     if (!t || !curve_ok(curve_id) || !label || !out_le32) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) fr_to_le<Bls381Fr>(Ipp<Bls381>::challenge_scalar(t->t, label), out_le32);
     else fr_to_le<Bn254Fr>(Ipp<Bn254>::challenge_scalar(t->t, label), out_le32);
     return BP_OK;
+    });
 }
 
 // ---- host Fr helpers ----------------------------------------------------------------------------------------
 int bp_fr_inverse(int curve_id, const uint8_t* in_le32, uint8_t* out_le32) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || !in_le32 || !out_le32) return BP_ERR_ARG;
     if (curve_id == BP_CURVE_BLS12_381) fr_to_le<Bls381Fr>(fr_inv_fast<Bls381Fr>(fr_from_le<Bls381Fr>(in_le32)), out_le32);
     else fr_to_le<Bn254Fr>(fr_inv_fast<Bn254Fr>(fr_from_le<Bn254Fr>(in_le32)), out_le32);
     return BP_OK;
+    });
 }
 
 // FieldElement::random() (src/r1cs/verifier.rs:392 and the provers' blindings): n uniform non-zero scalars from the OS
 // (getrandom), by rejection of fr_bits-bit draws.
 int bp_fr_random(int curve_id, uint8_t* out_le32, size_t n) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || (!out_le32 && n)) return BP_ERR_ARG;
     const int bits = curve_id == BP_CURVE_BLS12_381 ? Bls381Fr::BITS : Bn254Fr::BITS;
     for (size_t i = 0; i < n; i++) {
@@ -941,9 +960,11 @@ int bp_fr_random(int curve_id, uint8_t* out_le32, size_t n) {
         }
     }
     return BP_OK;
+    });
 }
 
 int bp_fr_is_canonical_nonzero(int curve_id, const uint8_t* x_le32) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || !x_le32) return 0;
     uint32_t w[8];
     memcpy(w, x_le32, 32);
@@ -951,10 +972,12 @@ int bp_fr_is_canonical_nonzero(int curve_id, const uint8_t* x_le32) {
     for (int i = 0; i < 8; i++) any |= w[i];
     if (!any) return 0;
     return curve_id == BP_CURVE_BLS12_381 ? (int)words_lt_mod<Bls381Fr>(w) : (int)words_lt_mod<Bn254Fr>(w);
+    });
 }
 
 // ---- FieldElementVector kernels -----------------------------------------------------------------------------
 int bp_fr_inner_product(bp_ctx* ctx, const bp_frvec* a, size_t aoff, const bp_frvec* b, size_t boff, size_t n, uint8_t* out_le32) {
+    return bp_guard([&]() -> int {
     if (!ctx || !a || !b || !out_le32) return BP_ERR_ARG;
     if (aoff > a->n || n > a->n - aoff || boff > b->n || n > b->n - boff) return BP_ERR_LENGTH;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
@@ -966,9 +989,11 @@ int bp_fr_inner_product(bp_ctx* ctx, const bp_frvec* a, size_t aoff, const bp_fr
     HIPCHK(hipMemcpyAsync(out_le32, part, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BP_OK;
+    });
 }
 
 int bp_fr_hadamard(bp_ctx* ctx, const bp_frvec* a, const bp_frvec* b, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !a || !b || !out) return BP_ERR_ARG;
     if (a->n != b->n) return BP_ERR_LENGTH;
     int rc = alloc_frvec(ctx, a->n, out); if (rc) return rc;
@@ -979,9 +1004,11 @@ int bp_fr_hadamard(bp_ctx* ctx, const bp_frvec* a, const bp_frvec* b, bp_frvec**
         hipLaunchKernelGGL(k_fr_hadamard<Bn254>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, (const ScalarWords*)b->d, a->n, (ScalarWords*)(*out)->d);
     HIPCHK(hipGetLastError());
     return BP_OK;
+    });
 }
 
 int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !a || !s_le32 || !out) return BP_ERR_ARG;
     int rc = alloc_frvec(ctx, a->n, out); if (rc) return rc;
     if (a->n == 0) return BP_OK;
@@ -991,9 +1018,11 @@ int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_fr
         hipLaunchKernelGGL(k_fr_scale<Bn254>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(s_le32)), a->n, (ScalarWords*)(*out)->d);
     HIPCHK(hipGetLastError());
     return BP_OK;
+    });
 }
 
 int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !e_le32 || !out) return BP_ERR_ARG;
     int rc = alloc_frvec(ctx, n, out); if (rc) return rc;
     if (n == 0) return BP_OK;
@@ -1003,6 +1032,7 @@ int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** o
         hipLaunchKernelGGL(k_fr_vandermonde<Bn254>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(e_le32)), n, (ScalarWords*)(*out)->d);
     HIPCHK(hipGetLastError());
     return BP_OK;
+    });
 }
 
 // ---- vector polynomials (src/utils/vector_poly.rs) ----------------------------------------------------------
@@ -1014,6 +1044,7 @@ static int same_len(const bp_frvec* const* v, int k, size_t* n) {
 }
 
 int bp_vecpoly3_special_inner_product(bp_ctx* ctx, const bp_frvec* const lhs[4], const bp_frvec* const rhs[4], uint8_t* out_t1_to_t6) {
+    return bp_guard([&]() -> int {
     if (!ctx || !lhs || !rhs || !out_t1_to_t6) return BP_ERR_ARG;
     size_t n, n2;
     int rc;
@@ -1039,9 +1070,11 @@ int bp_vecpoly3_special_inner_product(bp_ctx* ctx, const bp_frvec* const lhs[4],
     HIPCHK(hipMemcpyAsync(out_t1_to_t6, out, 6 * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BP_OK;
+    });
 }
 
 int bp_vecpoly1_inner_product(bp_ctx* ctx, const bp_frvec* const l[2], const bp_frvec* const r[2], uint8_t* out_t0_t1_t2) {
+    return bp_guard([&]() -> int {
     if (!ctx || !l || !r || !out_t0_t1_t2) return BP_ERR_ARG;
     size_t n, n2;
     int rc;
@@ -1067,9 +1100,11 @@ int bp_vecpoly1_inner_product(bp_ctx* ctx, const bp_frvec* const l[2], const bp_
     HIPCHK(hipMemcpyAsync(out_t0_t1_t2, out, 3 * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BP_OK;
+    });
 }
 
 int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uint8_t* x_le32, bp_frvec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !p || !x_le32 || !out || (degree != 1 && degree != 3)) return BP_ERR_ARG;
     size_t n;
     int rc;
@@ -1086,11 +1121,13 @@ int bp_vecpoly_eval(bp_ctx* ctx, const bp_frvec* const* p, int degree, const uin
                            fr_mont_words<Bn254Fr>(fr_from_le<Bn254Fr>(x_le32)), n, (ScalarWords*)(*out)->d);
     HIPCHK(hipGetLastError());
     return BP_OK;
+    });
 }
 
 // ---- R1CS vector pipeline (src/r1cs/prover.rs:458-563, src/r1cs/verifier.rs:342-390) ------------------------
 
 int bp_r1cs_prover_polys(bp_ctx* ctx, const bp_frvec* const in[8], const uint8_t* y_le32, bp_frvec* out[6]) {
+    return bp_guard([&]() -> int {
     if (!ctx || !in || !y_le32 || !out) return BP_ERR_ARG;
     size_t n;
     int rc;
@@ -1102,11 +1139,13 @@ int bp_r1cs_prover_polys(bp_ctx* ctx, const bp_frvec* const in[8], const uint8_t
     rc = ctx->curve == BP_CURVE_BLS12_381 ? r1cs_prover_polys_impl<Bls381>(ctx, in, y_le32, n, out) : r1cs_prover_polys_impl<Bn254>(ctx, in, y_le32, n, out);
     if (rc) for (int k = 0; k < 6; k++) { bp_frvec_free(out[k]); out[k] = nullptr; }
     return rc;
+    });
 }
 
 
 int bp_r1cs_ipp_inputs(bp_ctx* ctx, const bp_frvec* l_eval, const bp_frvec* r_eval, const uint8_t* y_le32, const uint8_t* u_le32, size_t n1,
                        size_t padded_n, bp_frvec* out[4]) {
+    return bp_guard([&]() -> int {
     if (!ctx || !l_eval || !r_eval || !y_le32 || !u_le32 || !out) return BP_ERR_ARG;
     if (l_eval->n != r_eval->n) return BP_ERR_LENGTH;
     if (padded_n < l_eval->n || n1 > l_eval->n || padded_n == 0 || (padded_n & (padded_n - 1))) return BP_ERR_ARG;
@@ -1117,6 +1156,7 @@ int bp_r1cs_ipp_inputs(bp_ctx* ctx, const bp_frvec* l_eval, const bp_frvec* r_ev
                                           : r1cs_ipp_inputs_impl<Bn254>(ctx, l_eval, r_eval, y_le32, u_le32, n1, padded_n, out);
     if (rc) for (int k = 0; k < 4; k++) { bp_frvec_free(out[k]); out[k] = nullptr; }
     return rc;
+    });
 }
 
 
@@ -1124,6 +1164,7 @@ int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le,
                              const bp_frvec* wL, const bp_frvec* wR, const bp_frvec* wO, const uint8_t* y_inv_le32, const uint8_t* x_le32,
                              const uint8_t* u_le32, const uint8_t* a_le32, const uint8_t* b_le32, uint8_t* u_sq_out, uint8_t* u_inv_sq_out,
                              bp_frvec** g_scalars, bp_frvec** h_scalars) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !wL || !wR || !wO || !y_inv_le32 || !x_le32 || !u_le32 || !a_le32 || !b_le32 || !u_sq_out || !u_inv_sq_out || !g_scalars ||
         !h_scalars || (lg_n && (!L_le || !R_le)))
         return BP_ERR_ARG;
@@ -1141,10 +1182,12 @@ int bp_r1cs_verifier_scalars(bp_ctx* ctx, bp_transcript* t, const uint8_t* L_le,
                                                  u_sq_out, u_inv_sq_out, *g_scalars, *h_scalars);
     if (rc) { bp_frvec_free(*g_scalars); bp_frvec_free(*h_scalars); *g_scalars = *h_scalars = nullptr; }
     return rc;
+    });
 }
 
 // ---- IPP device-resident state ------------------------------------------------------------------------------
 int bp_ipp_state_free(bp_ipp_state* st) {
+    return bp_guard([&]() -> int {
     if (!st) return BP_OK;
     if (st->side_pending) (void)hipEventSynchronize(st->ev_side);      // blocks in use on the sibling stream must not return to the pool yet
     if (st->ev_side) (void)hipEventDestroy(st->ev_side);
@@ -1155,10 +1198,12 @@ int bp_ipp_state_free(bp_ipp_state* st) {
     }
     delete st;
     return BP_OK;
+    });
 }
 
 int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* Q_le, const bp_frvec* Gf, const bp_frvec* Hf,
                         const bp_frvec* a, const bp_frvec* b, bp_ipp_state** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !G || !H || !Q_le || !Gf || !Hf || !a || !b || !out) return BP_ERR_ARG;
     *out = nullptr;
     size_t n = G->n;
@@ -1246,41 +1291,51 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
     }
     *out = st;
     return BP_OK;
+    });
 }
 
 size_t bp_ipp_state_len(const bp_ipp_state* st) { return st ? st->n : 0; }
 
 int bp_ctx_set_ipp_fold_generators(bp_ctx* ctx, int on) {
+    return bp_guard([&]() -> int {
     if (!ctx) return BP_ERR_ARG;
     ctx->ipp_fold_generators = on != 0;
     return BP_OK;
+    });
 }
 
 int bp_ipp_round(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
+    return bp_guard([&]() -> int {
     if (!st || !L_le || !R_le || st->n < 2) return BP_ERR_ARG;
     int rc = bp_internal_set_device(st->ctx); if (rc) return rc;
     IPP_DISPATCH(st->ctx->curve, I::round(st, L_le, R_le));
+    });
 }
 
 int bp_ipp_fold(bp_ipp_state* st, const uint8_t* u_le32, const uint8_t* u_inv_le32) {
+    return bp_guard([&]() -> int {
     if (!st || !u_le32 || !u_inv_le32 || st->n < 2) return BP_ERR_ARG;
     int rc = bp_internal_set_device(st->ctx); if (rc) return rc;
     IPP_DISPATCH(st->ctx->curve, I::fold(st, u_le32, u_inv_le32));
+    });
 }
 
 int bp_ipp_state_finish(bp_ipp_state* st, uint8_t* a_le32, uint8_t* b_le32) {
+    return bp_guard([&]() -> int {
     if (!st || !a_le32 || !b_le32 || st->n != 1) return BP_ERR_ARG;
     int rc = bp_internal_set_device(st->ctx); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(a_le32, st->a, 32, hipMemcpyDeviceToHost, st->ctx->stream));
     HIPCHK(hipMemcpyAsync(b_le32, st->b, 32, hipMemcpyDeviceToHost, st->ctx->stream));
     HIPCHK(hipStreamSynchronize(st->ctx->stream));
     return BP_OK;
+    });
 }
 
 // ---- IPP::create_ipp / verify_ipp with the library's host transcript ----------------------------------------
 int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
                   const bp_g1vec* H, const bp_frvec* a, const bp_frvec* b, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out_le32,
                   uint8_t* b_out_le32) {
+    return bp_guard([&]() -> int {
     if (!t || !a_out_le32 || !b_out_le32) return BP_ERR_ARG;
     bp_ipp_state* st = nullptr;
     int rc = bp_ipp_state_create(ctx, G, H, Q_le, G_factors, H_factors, a, b, &st);
@@ -1290,11 +1345,13 @@ int bp_ipp_create(bp_ctx* ctx, bp_transcript* t, const uint8_t* Q_le, const bp_f
     else rc = Ipp<Bn254>::create(st, t->t, L_out, R_out, lg_n_out, a_out_le32, b_out_le32);
     bp_ipp_state_free(st);
     return rc;
+    });
 }
 
 int bp_ipp_create_multi(bp_ctx* const* ctxs, size_t n_shards, bp_transcript* t, const uint8_t* Q_le, const bp_frvec* const* G_factors,
                         const bp_frvec* const* H_factors, const bp_g1vec* const* G, const bp_g1vec* const* H, const uint8_t* a_le32,
                         const uint8_t* b_le32, size_t n, uint8_t* L_out, uint8_t* R_out, size_t* lg_n_out, uint8_t* a_out_le32, uint8_t* b_out_le32) {
+    return bp_guard([&]() -> int {
     if (!ctxs || n_shards == 0 || n_shards > 64 || !t || !Q_le || !G_factors || !H_factors || !G || !H || !a_le32 || !b_le32 || !a_out_le32 || !b_out_le32)
         return BP_ERR_ARG;
     if (n == 0 || (n & (n - 1))) return BP_ERR_ARG;                                             // assert!(n.is_power_of_two())  ipp.rs:48
@@ -1315,20 +1372,24 @@ int bp_ipp_create_multi(bp_ctx* const* ctxs, size_t n_shards, bp_transcript* t, 
         for (size_t s = 0; s < n_shards; s++) { (void)bp_internal_set_device(ctxs[s]); (void)hipStreamSynchronize(ctxs[s]->stream); }
         return BP_ERR_DEVICE;
     }
+    });
 }
 
 int bp_ipp_verify(bp_ctx* ctx, bp_transcript* t, size_t n, const bp_frvec* G_factors, const bp_frvec* H_factors, const uint8_t* P_le,
                   const uint8_t* Q_le, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* a_le32, const uint8_t* b_le32, const uint8_t* L_le,
                   const uint8_t* R_le, size_t lg_n) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !G_factors || !H_factors || !P_le || !Q_le || !G || !H || !a_le32 || !b_le32 || (lg_n && (!L_le || !R_le))) return BP_ERR_ARG;
     if (lg_n >= 32 || n != ((size_t)1 << lg_n)) return BP_ERR_VERIFY;           // verification_scalars, ipp.rs:269-276
     if (G->n < n || H->n < n || G_factors->n < n || H_factors->n < n) return BP_ERR_LENGTH;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     IPP_DISPATCH(ctx->curve, I::verify(ctx, t->t, n, G_factors, H_factors, P_le, Q_le, G, H, a_le32, b_le32, L_le, R_le, lg_n));
+    });
 }
 
 int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_factors, const bp_frvec* H_factors, const bp_g1vec* G,
                         const bp_g1vec* H, const bp_ipp_proof_ref* proofs, size_t m, const uint8_t* weights_le32) {
+    return bp_guard([&]() -> int {
     if (!ctx || !G_factors || !H_factors || !G || !H || (m && !proofs)) return BP_ERR_ARG;
     // weights: the caller's (tests) or, with NULL, fresh ones from the OS; a zero weight would drop its proof from the check
     std::vector<uint8_t> wbuf;
@@ -1349,9 +1410,11 @@ int bp_ipp_verify_batch(bp_ctx* ctx, size_t n, size_t lg_n, const bp_frvec* G_fa
     if (m == 0) return BP_OK;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     IPP_DISPATCH(ctx->curve, I::verify_batch(ctx, n, lg_n, G_factors, H_factors, G, H, proofs, m, weights_le32));
+    });
 }
 
 int bp_g1vec_commit_pairs(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const bp_frvec* k1, const bp_frvec* k2, bp_g1vec** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !g_le || !h_le || !k1 || !k2 || !out) return BP_ERR_ARG;
     *out = nullptr;
     if (k1->n != k2->n) return BP_ERR_LENGTH;
@@ -1361,10 +1424,12 @@ int bp_g1vec_commit_pairs(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le,
     else rc = commit_pairs_impl<Bn254>(ctx, g_le, h_le, k1, k2, *out);
     if (rc) { bp_g1vec_free(*out); *out = nullptr; }
     return rc;
+    });
 }
 
 int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constraint, const uint8_t* term_kind, const uint32_t* term_index,
                         const uint8_t* coeff_le32, size_t n_constraints, size_t n, size_t m, bp_r1cs_plan** out) {
+    return bp_guard([&]() -> int {
     if (!ctx || !out || (n_terms && (!term_constraint || !term_kind || !term_index || !coeff_le32))) return BP_ERR_ARG;
     *out = nullptr;
     if (n_terms >= ((size_t)1 << 32) || 3 * n + m + 1 >= ((size_t)1 << 32) || n_constraints >= ((size_t)1 << 32)) return BP_ERR_ARG;
@@ -1405,28 +1470,34 @@ int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constr
         return fail();
     *out = p;
     return BP_OK;
+    });
 }
 
 int bp_r1cs_plan_free(bp_r1cs_plan* p) {
+    return bp_guard([&]() -> int {
     if (!p) return BP_OK;
     (void)hipSetDevice(p->device);
     for (void* b : {p->seg, p->tq, p->coeff, p->heavy}) if (b) (void)hipFree(b);
     delete p;
     return BP_OK;
+    });
 }
 
 int bp_r1cs_flattened_constraints(bp_ctx* ctx, const bp_r1cs_plan* plan, const uint8_t* z_le32, bp_frvec* out[4], uint8_t* wc_le32) {
+    return bp_guard([&]() -> int {
     if (!ctx || !plan || !z_le32 || !out) return BP_ERR_ARG;
     for (int k = 0; k < 4; k++) out[k] = nullptr;
     if (plan->curve != ctx->curve || plan->device != ctx->device) return BP_ERR_ARG;
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     if (ctx->curve == BP_CURVE_BLS12_381) return flattened_constraints_impl<Bls381>(ctx, plan, z_le32, out, wc_le32);
     return flattened_constraints_impl<Bn254>(ctx, plan, z_le32, out, wc_le32);
+    });
 }
 
 // IPP::verification_scalars (ipp.rs:262-315): (u_j^2, u_j^-2, s) as canonical LE scalars; host arithmetic.
 int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L_le, const uint8_t* R_le, size_t lg_n, size_t n, uint8_t* u_sq,
                                 uint8_t* u_inv_sq, uint8_t* s) {
+    return bp_guard([&]() -> int {
     if (!curve_ok(curve_id) || !t || !u_sq || !u_inv_sq || !s || (lg_n && (!L_le || !R_le))) return BP_ERR_ARG;
     auto run = [&](auto tag) -> int {
         using C = decltype(tag);
@@ -1452,6 +1523,7 @@ int bp_ipp_verification_scalars(int curve_id, bp_transcript* t, const uint8_t* L
         return BP_OK;
     };
     return curve_id == BP_CURVE_BLS12_381 ? run(Bls381{}) : run(Bn254{});
+    });
 }
 
 }  // extern "C"

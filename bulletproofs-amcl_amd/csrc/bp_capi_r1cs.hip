@@ -428,6 +428,7 @@ size_t bp_r1cs_proof_bytes(int curve_id, size_t n) {
 int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                   const uint8_t* h_le, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O, const bp_frvec* v_blinding, const bp_frvec* s_L,
                   const bp_frvec* s_R, const uint8_t* blindings_le32, uint8_t* proof_out, size_t proof_cap) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || !a_L || !a_R || !a_O || !s_L || !s_R || !blindings_le32 || !proof_out) return BP_ERR_ARG;
     const size_t n = a_L->n;
     if (n == 0 || a_R->n != n || a_O->n != n || s_L->n != n || s_R->n != n) return BP_ERR_LENGTH;
@@ -438,10 +439,12 @@ int bp_r1cs_prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::prove(ctx, t, plan, G, H, g_le, h_le, a_L, a_R, a_O, v_blinding, s_L, s_R, blindings_le32, proof_out);
     return R1cs<Bn254>::prove(ctx, t, plan, G, H, g_le, h_le, a_L, a_R, a_O, v_blinding, s_L, s_R, blindings_le32, proof_out);
+    });
 }
 
 int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                    const uint8_t* h_le, const uint8_t* V_le, size_t n, size_t m, const uint8_t* proof, size_t proof_len, const uint8_t* r_le32) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || (m && !V_le) || !proof || n == 0) return BP_ERR_ARG;
     if (proof_len != bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_VERIFY;
     size_t pn = 1;
@@ -458,6 +461,7 @@ int bp_r1cs_verify(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, cons
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
     return R1cs<Bn254>::verify(ctx, t, plan, G, H, g_le, h_le, V_le, n, m, proof, r_le32);
+    });
 }
 
 // ---- two-phase (randomised) constraint systems: the same functions split where the reference runs the deferred callbacks -------
@@ -476,6 +480,7 @@ size_t bp_r1cs_phase1_bytes(void) { return sizeof(Phase1Blob); }
 int bp_r1cs_prove_begin(bp_ctx* ctx, bp_transcript* t, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* h_le, size_t m, const bp_frvec* a_L1,
                         const bp_frvec* a_R1, const bp_frvec* a_O1, const bp_frvec* s_L1, const bp_frvec* s_R1, const uint8_t* blindings3_le32,
                         uint8_t* phase1_out, size_t phase1_cap) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !G || !H || !h_le || !blindings3_le32 || !phase1_out) return BP_ERR_ARG;
     if (phase1_cap < sizeof(Phase1Blob)) return BP_ERR_LENGTH;
     const size_t n1 = a_L1 ? a_L1->n : 0;
@@ -496,12 +501,14 @@ int bp_r1cs_prove_begin(bp_ctx* ctx, bp_transcript* t, const bp_g1vec* G, const 
     RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-2phase", 11));      // prover.rs:308
     memcpy(phase1_out, &b, sizeof b);
     return BP_OK;
+    });
 }
 
 int bp_r1cs_prove_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                          const uint8_t* h_le, const uint8_t* phase1, const bp_frvec* a_L, const bp_frvec* a_R, const bp_frvec* a_O,
                          const bp_frvec* v_blinding, const bp_frvec* s_L, const bp_frvec* s_R, const uint8_t* blindings8_le32, uint8_t* proof_out,
                          size_t proof_cap) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || !phase1 || !a_L || !a_R || !a_O || !s_L || !s_R || !blindings8_le32 || !proof_out) return BP_ERR_ARG;
     Phase1Blob b;
     memcpy(&b, phase1, sizeof b);
@@ -524,19 +531,23 @@ int bp_r1cs_prove_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan
     memcpy(proof_out, b.points, 3 * R1cs<Bn254>::pb);
     return R1cs<Bn254>::prove_tail(ctx, T, t, plan, G, H, g_le, h_le, (size_t)b.n1, a_L, a_R, a_O, v_blinding, s_L, s_R, b.blindings, blindings8_le32,
                                    blindings8_le32 + 96, proof_out);
+    });
 }
 
 int bp_r1cs_verify_begin(bp_transcript* t, int curve_id, size_t m, const uint8_t* proof, size_t proof_len) {
+    return bp_guard([&]() -> int {
     if (!t || !proof || !curve_ok(curve_id)) return BP_ERR_ARG;
     const size_t pb = curve_id == BP_CURVE_BLS12_381 ? R1cs<Bls381>::pb : R1cs<Bn254>::pb;
     if (proof_len < 3 * pb) return BP_ERR_VERIFY;
     RC(curve_id == BP_CURVE_BLS12_381 ? R1cs<Bls381>::verify_phase1(t, curve_id, m, proof) : R1cs<Bn254>::verify_phase1(t, curve_id, m, proof));
     return bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-2phase", 11);  // verifier.rs:253
+    });
 }
 
 int bp_r1cs_verify_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                           const uint8_t* h_le, const uint8_t* V_le, size_t n1, size_t n, size_t m, const uint8_t* proof, size_t proof_len,
                           const uint8_t* r_le32) {
+    return bp_guard([&]() -> int {
     if (!ctx || !t || !plan || !G || !H || !g_le || !h_le || (m && !V_le) || !proof || n == 0 || n1 > n) return BP_ERR_ARG;
     if (proof_len != bp_r1cs_proof_bytes(ctx->curve, n)) return BP_ERR_VERIFY;
     size_t pn = 1;
@@ -551,6 +562,7 @@ int bp_r1cs_verify_finish(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* pla
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     if (ctx->curve == BP_CURVE_BLS12_381) return R1cs<Bls381>::verify_tail(ctx, t, plan, G, H, g_le, h_le, V_le, n1, n, m, proof, r_le32);
     return R1cs<Bn254>::verify_tail(ctx, t, plan, G, H, g_le, h_le, V_le, n1, n, m, proof, r_le32);
+    });
 }
 
 }  // extern "C"

@@ -132,6 +132,7 @@ struct bp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int c_override = 0;
+    int win_first = 0, win_count = 0;   // window group of the MSM being queued (bp_msm_g1_windows_subset sets and clears them); 0 = all windows
     bp_tuning tuning;
     bool timing = false;
     bool pending = false;               // bp_msm_g1_begin issued, bp_msm_g1_end not yet called
@@ -241,6 +242,12 @@ extern "C" void bp_internal_table_free(bp_g1table* t);
 int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out);
 // compaction table of a vector from its window-multiples table (bp_capi_ipp.hip); *out stays NULL when the width does not divide 64
 int bp_internal_ctable_build(bp_ctx* ctx, const bp_g1table* wt, bp_g1table** out);
+
+// No exception crosses the C ABI: every multi-line `int bp_*` entry point runs its body inside this guard -- a
+// std::bad_alloc from a std::vector in the host orchestration (or anything else) becomes BP_ERR_DEVICE.
+template <class F> static inline int bp_guard(F&& body) noexcept {
+    try { return body(); } catch (...) { return BP_ERR_DEVICE; }
+}
 
 static inline int fp_bytes_of(int curve) { return curve == BP_CURVE_BLS12_381 ? 48 : 32; }
 static inline bool curve_ok(int curve) { return curve == BP_CURVE_BLS12_381 || curve == BP_CURVE_BN254; }

@@ -92,6 +92,20 @@ __device__ __forceinline__ void add256(uint64_t (&q)[4], const ScalarWords& a, c
     }
 }
 
+// q >>= k, 0 < k < 256 (k wave-uniform: the branches are scalar)
+__device__ __forceinline__ void shr256(uint64_t (&q)[4], int k) {
+    const int word = k >> 6, sh = k & 63;
+    if (word == 1) { q[0] = q[1]; q[1] = q[2]; q[2] = q[3]; q[3] = 0; }
+    else if (word == 2) { q[0] = q[2]; q[1] = q[3]; q[2] = 0; q[3] = 0; }
+    else if (word == 3) { q[0] = q[3]; q[1] = 0; q[2] = 0; q[3] = 0; }
+    if (sh) {
+        q[0] = (q[0] >> sh) | (q[1] << (64 - sh));
+        q[1] = (q[1] >> sh) | (q[2] << (64 - sh));
+        q[2] = (q[2] >> sh) | (q[3] << (64 - sh));
+        q[3] >>= sh;
+    }
+}
+
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* lds, uint32_t& block_total);
 
 // Sorting point indices by (window, bucket) -- a two-level binning sort, all atomics in LDS:
@@ -131,6 +145,7 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
             if (e0 + u < per && i < n) {
                 uint64_t q[4];
                 add256(q, sw[u], tab.bias);
+                if (const int off0 = tab.off[set * wps]) shr256(q, off0);      // a window SUBSET (sharded callers): its first window starts above bit 0
                 for (int w = set * wps; w < (set + 1) * wps; w++) {
                     int c = tab.cw[w];
                     uint32_t raw = (uint32_t)q[0] & ((1u << c) - 1);

@@ -222,6 +222,21 @@ size_t bp_msm_record_bytes(int curve_id);
 int bp_msm_g1_windows(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n,
                       void* device_out);
 int bp_msm_g1_finish(bp_ctx* ctx, const void* device_records, size_t sets, size_t n_per_set, uint8_t* out_le);
+/* ---- 2-D sharding (round 4): index range x WINDOW GROUP.  The index-range split leaves every shard with all W windows, i.e. with the
+ * full bucket reduce, sort and host tail however short its slice is; a shard may instead take the windows [w_first, w_first + w_count)
+ * of the same recoding over a LONGER slice (N = 8 as 2 x 4: half of the points, 4 of 16 windows each).  Its block holds
+ * block_records records: the group's tail records (bp_msm_window_records_subset - 1 of them), zero padding, and the geometry header --
+ * which names the window group -- as the LAST record.  The context's window width must be fixed (bp_ctx_set_window_bits) when the
+ * slices differ in length.  bp_msm_g1_finish_blocks folds any mix of blocks: every index range must be covered by groups that
+ * together hold all W windows exactly once (checked as far as the blocks can tell: every window must occur in the same number of
+ * blocks); headers that do not fit the caller's geometry, window groups that do not tile the windows: BP_ERR_ARG.  /root/reference call site: multi_scalar_mul_var_time, src/ipp.rs:251-253. */
+size_t bp_msm_window_records_subset(bp_ctx* ctx, size_t n, int w_first, int w_count);
+int bp_msm_g1_windows_subset(bp_ctx* ctx, const bp_g1vec* points, size_t poff, const bp_frvec* scalars, size_t soff, size_t n, int w_first, int w_count,
+                             size_t block_records, void* device_out);
+int bp_msm_g1_finish_blocks(bp_ctx* ctx, const void* device_records, size_t n_blocks, size_t block_records, size_t n_per_set, uint8_t* out_le);
+int bp_msm_g1_finish_blocks_host(int curve_id, const void* host_records, size_t n_blocks, size_t block_records, size_t n_per_set, int window_bits, uint8_t* out_le);
+int bp_msm_record_positions_subset(int curve_id, size_t n, int window_bits, int w_first, int w_count, int* nrec_out, uint16_t* pos_out);
+int bp_msm_record_header_subset(int curve_id, size_t n, int window_bits, int w_first, int w_count, void* record_out);
 /* Stage 2 on HOST memory, no GPU needed (an aggregator that only receives record blocks): same validation and fold.
  * window_bits: 0 = the width chosen from n_per_set, else the common width the ranks fixed. */
 int bp_msm_g1_finish_host(int curve_id, const void* host_records, size_t sets, size_t n_per_set, int window_bits, uint8_t* out_le);

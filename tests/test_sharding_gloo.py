@@ -57,6 +57,33 @@ try:
     bp.msm_finish_host(curve, bytes(bad), world, nmax, c); raise SystemExit("geometry mismatch was not detected")
 except bp.ArgError:
     pass
+# ---- 2-D mode (round 4): ONE index group, the WINDOWS split over the ranks -- every rank all points, half of the windows; blocks carry
+# their window group in the header and bp_msm_g1_finish_blocks_host adds what it is given
+ig, wg = sharding.plan_2d(world, len(cw))
+assert (ig, wg) == (1, world)
+lo2, hi2, w0, wn = sharding.shard_2d(n, world, rank, len(cw))
+assert (lo2, hi2) == (0, n) and wn == len(cw) // world and w0 == rank * wn
+c2, cw2, off2, bias2 = bp.msm_geometry(curve, n, 0)
+stride = 1 + max(len(bp.msm_record_positions_subset(curve, n, c2, g * wn, wn)) for g in range(world))
+pos2 = bp.msm_record_positions_subset(curve, n, c2, w0, wn)
+recs2 = [zero] * (stride - 1)
+for w in range(w0, w0 + wn):
+    digs = b""
+    for i in range(n):
+        k = int.from_bytes(ss[32 * i:32 * i + 32], "little") + bias2
+        d = ((k >> off2[w]) & ((1 << cw2[w]) - 1)) - ((1 << (cw2[w] - 1)) - 1)
+        digs += (d %% r).to_bytes(32, "little")
+    S = O.msm(curve, pts, digs, n, algo=O.PIPPENGER)
+    slot = next(j for j in range(len(pos2)) if pos2[j] == off2[w] and recs2[j] is zero)
+    recs2[slot] = bp.msm_record_from_affine(curve, S)
+block2 = b"".join(recs2) + bp.msm_record_header_subset(curve, n, c2, w0, wn)
+all2 = sharding.all_gather_records(torch.frombuffer(bytearray(block2), dtype=torch.uint8), world)
+assert bp.msm_finish_blocks_host(curve, bytes(all2.tolist()), world, stride, n, c2) == want, "window-sharded sum differs"
+bad = bytearray(bytes(all2.tolist())); bad[len(block2) - 192 + 40] ^= 1          # the header's window group
+try:
+    bp.msm_finish_blocks_host(curve, bytes(bad), world, stride, n, c2); raise SystemExit("a damaged window group was not detected")
+except bp.ArgError:
+    pass
 t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == world
 dist.barrier(); dist.destroy_process_group()
 sys.stdout.write("rank-%%d-ok\n" %% rank); sys.stdout.flush()
