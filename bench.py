@@ -149,29 +149,43 @@ def h2d_headline(bp, ctx, torch, pts, s_bytes, n, expect, steps):
     return res
 
 
-def strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=22, steps=5, warmup=1):
-    """BASELINE config 4 inside the weak run: 2^22 points IN TOTAL split by index range over the ranks, timed like the main value
-    (barrier + synchronize on both sides, max over ranks) and verified against the oracle on rank 0."""
+def strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=22, steps=5, warmup=1, window_groups=1):
+    """BASELINE config 4 inside the weak run: 2^22 points IN TOTAL split over the ranks, timed like the main value (barrier +
+    synchronize on both sides, max over ranks) and verified against the oracle on rank 0.  window_groups = 1: by index range (what
+    north_star names); > 1: index range x window group (sharding.shard_2d) -- world / window_groups index groups, every rank
+    1 / window_groups of the windows of a window_groups times longer slice."""
     import _oracle as O
     n_total = 1 << lg_total
-    lo, hi = sharding.shard_range(n_total, world, rank)
+    igroups = world // window_groups
+    grp = rank // window_groups                        # index group of this rank (ranks of one group hold the same points)
+    lo, hi = sharding.shard_range(n_total, igroups, grp)
     n = hi - lo
-    n_set = sharding.largest_shard(n_total, world)
-    if n_total % world:
-        ctx.set_window_bits(sharding.common_window_bits(bp, curve, n_total, world))
-    seed_of = lambda rk: 0xC0F164 + 2 * rk
-    kb = random_scalars(ctx.r, info.fr_bits, n, seed_of(rank))
-    sb = random_scalars(ctx.r, info.fr_bits, n, seed_of(rank) + 1)
+    n_set = sharding.largest_shard(n_total, igroups)
+    if n_total % igroups or window_groups > 1:
+        ctx.set_window_bits(sharding.common_window_bits(bp, curve, n_total, igroups))
+    seed_of = lambda g: 0xC0F164 + 2 * g
+    kb = random_scalars(ctx.r, info.fr_bits, n, seed_of(grp))
+    sb = random_scalars(ctx.r, info.fr_bits, n, seed_of(grp) + 1)
     pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, kb, n))
     sv = bp.FieldElementVector.from_bytes(ctx, sb, n)
     ctx.synchronize()
-    W = bp.msm_window_records(ctx, n_set)
+    if window_groups > 1:
+        nwin = len(bp.msm_geometry(curve, n_set, sharding.common_window_bits(bp, curve, n_total, igroups))[1])
+        _, _, w0, wn = sharding.shard_2d(n_total, world, rank, nwin, window_groups)
+        W = max(bp.msm_window_records_subset(ctx, n_set, g * wn, wn) for g in range(window_groups))
+    else:
+        W = bp.msm_window_records(ctx, n_set)
     mine = torch.zeros(W * bp.msm_record_bytes(curve), dtype=torch.uint8, device=dev)
 
     def step():
-        bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
+        if window_groups > 1:
+            bp.msm_windows_subset(ctx, pts, 0, sv, 0, n, w0, wn, W, mine.data_ptr())
+        else:
+            bp.msm_windows(ctx, pts, 0, sv, 0, n, mine.data_ptr())
         allrec = sharding.all_gather_records(mine, world)
         torch.cuda.current_stream(dev).synchronize()
+        if window_groups > 1:
+            return bp.msm_finish_blocks(ctx, allrec.data_ptr(), world, W, n_set)
         return bp.msm_finish(ctx, allrec.data_ptr(), world, n_set)
 
     def fence():
@@ -193,14 +207,17 @@ def strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dis
     out = None
     if rank == 0:
         acc = 0
-        for rk in range(world):
-            a, b = sharding.shard_range(n_total, world, rk)
-            k2 = kb if rk == 0 else random_scalars(ctx.r, info.fr_bits, b - a, seed_of(rk))
-            s2 = sb if rk == 0 else random_scalars(ctx.r, info.fr_bits, b - a, seed_of(rk) + 1)
+        for g in range(igroups):
+            a, b = sharding.shard_range(n_total, igroups, g)
+            k2 = kb if g == 0 else random_scalars(ctx.r, info.fr_bits, b - a, seed_of(g))
+            s2 = sb if g == 0 else random_scalars(ctx.r, info.fr_bits, b - a, seed_of(g) + 1)
             acc = (acc + int.from_bytes(O.fr_inner(curve, k2, s2, b - a), "little")) % ctx.r
         want = O.g1_mul(curve, acc.to_bytes(32, "little"), O.generator(curve))
         ok = bool(result == want)
-        out = {"workload": "2^%d-point bls12_381 G1 MSM in total, index range split over %d GPUs (BASELINE config 4 shape)" % (lg_total, world),
+        how = "index range split over %d GPUs" % world if window_groups == 1 else \
+              "%d index groups x %d window groups over %d GPUs (every rank 1/%d of the windows of a 2^%d-point slice)" % (igroups, window_groups, world, window_groups, n_set.bit_length() - 1)
+        out = {"workload": "2^%d-point bls12_381 G1 MSM in total, %s (BASELINE config 4 shape)" % (lg_total, how),
+               "shard_mode": "index" if window_groups == 1 else "index_x_windows", "index_groups": igroups, "window_groups": window_groups,
                "scaling": "strong", "n_total": n_total, "n_per_gpu": n_set, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
                "value": n_total * steps / elapsed if ok else None, "unit": "scalar-muls/s", "verified": ok,
                "speedup_vs_1gpu_same_n": None,       # needs the N = 1 run's sweep["2^22"]: the driver has both lines, this one has not
@@ -224,6 +241,7 @@ def main():
     ap.add_argument("--extras", action="store_true", help="emit the extra keys although --lg-n is not the headline size (tests)")
     ap.add_argument("--sweep-max-lg", type=int, default=22, help="largest size of the N = 1 sweep (tests shrink it)")
     ap.add_argument("--strong-lg", type=int, default=22, help="log2 of the total size of the N > 1 strong-scaling extra (tests shrink it)")
+    ap.add_argument("--window-groups", type=int, default=0, help="window groups of the 2-D strong-scaling extra (0: 4 if the world size allows, else 2)")
     ap.add_argument("--configs-small", action="store_true", help="shrunk sizes for the \"configs\" extra (cfg1 / cfg3_e2e / cfg5; tests)")
     ap.add_argument("--overlap", action="store_true",
                     help="also time the same MSMs with two in flight (extra field; off by default so that rocprofv3 averages of the default "
@@ -497,6 +515,13 @@ def main():
         st = strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=args.strong_lg)
         if rank == 0:
             out["strong_2p%d" % args.strong_lg] = st
+        # the same total with the WINDOWS split as well (round 4; one-GPU timings of a rank's share, profiles/r04_shard_shapes.log:
+        # 8 x 1 -> 1.96 ms, 2 x 4 -> 1.77 ms per rank): 4 window groups where the world size allows, else 2
+        wg = args.window_groups if args.window_groups else (4 if world % 4 == 0 else 2 if world % 2 == 0 else 1)
+        if wg > 1 and world % wg == 0:
+            st2 = strong_extra(bp, sharding, ctx, curve, info, dev, world, rank, use_dist, dist, torch, args, lg_total=args.strong_lg, window_groups=wg)
+            if rank == 0:
+                out["strong_2p%d_index_x_windows" % args.strong_lg] = st2
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

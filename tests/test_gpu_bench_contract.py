@@ -64,7 +64,10 @@ def test_bench_extras_sweep_and_strong_keys():
     assert d["scaling"] == "weak" and d["verified"] is True and "sweep" not in d
     st = d["strong_2p16"]
     assert st["scaling"] == "strong" and st["n_total"] == 1 << 16 and st["n_per_gpu"] == 1 << 15 and st["verified"] is True
-    assert st["value"] > 0 and st["speedup_vs_1gpu_same_n"] is None
+    assert st["value"] > 0 and st["speedup_vs_1gpu_same_n"] is None and st["shard_mode"] == "index"
+    s2 = d["strong_2p16_index_x_windows"]                        # the 2-D mode (round 4): one index group, two window groups at N = 2
+    assert s2["shard_mode"] == "index_x_windows" and (s2["index_groups"], s2["window_groups"]) == (1, 2) and s2["n_per_gpu"] == 1 << 16
+    assert s2["verified"] is True and s2["value"] > 0
 
 
 def test_bench_self_launches_n_ranks_and_strong_scaling():
