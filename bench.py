@@ -413,13 +413,13 @@ def main():
         # library being benchmarked (profiles/README lists how it was taken); raw FETCH_SIZE + WRITE_SIZE (the guide's x2 read
         # correction is calibrated for wide streaming reads, not for 96-byte row gathers, so it is not applied).
         traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_bench_n1_pmc_hbm.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_bench_n1_pmc_hbm.json")
         if args.curve == "bls12_381" and args.lg_n == 20 and not args.strong and os.path.exists(pmc):
             pj = json.load(open(pmc))
             k = next((v for name, v in pj.get("kernels", {}).items() if ACC_KERNEL_PREFIX in name), {})
             if "FETCH_SIZE_KiB_avg" in k and "WRITE_SIZE_KiB_avg" in k:
                 traffic = int((k["FETCH_SIZE_KiB_avg"] + k["WRITE_SIZE_KiB_avg"]) * 1024)
-                traffic_note = "stored profile profiles/r03_bench_n1_pmc_hbm.json (%s): raw FETCH_SIZE + WRITE_SIZE per launch" % pj.get("taken", "?")
+                traffic_note = "stored profile profiles/r04_bench_n1_pmc_hbm.json (%s): raw FETCH_SIZE + WRITE_SIZE per launch" % pj.get("taken", "?")
         if acc_ms:
             avg = float(np.mean(acc_ms)) * 1e-3
             achieved = n * unit_bytes / avg / 1e9

@@ -18,7 +18,7 @@ _SO = os.environ.get("BPMSM_SO") or os.path.join(_HERE, "libbpmsm.so")   # overr
 BP_OK, BP_ERR_LENGTH, BP_ERR_ARG, BP_ERR_VERIFY, BP_ERR_DEVICE = 0, 1, 2, 3, 4
 BLS12_381, BN254 = 0, 1
 FMT_LE, FMT_AMCL = 0, 1
-TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM, TUNE_TAIL_CHAINS, TUNE_COMPACT_AT = 1, 2, 3, 4, 5, 6   # bp_ctx_set_tuning knobs (include/bpmsm.h)
+TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM, TUNE_TAIL_CHAINS, TUNE_COMPACT_AT, TUNE_GLV = 1, 2, 3, 4, 5, 6, 7   # bp_ctx_set_tuning knobs (include/bpmsm.h)
 CURVE_IDS = {"bls12_381": BLS12_381, "bn254": BN254}
 
 

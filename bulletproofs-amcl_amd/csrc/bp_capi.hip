@@ -265,6 +265,7 @@ struct Impl {
         // tb: window-multiples table of `pts` (same n): the merged-window pipeline over its rows
         const bp_g1table* dm = nullptr;                     // digit multiples for the single-launch small MSM (bp_g1table::digits)
         if (tb && tb->digits) { dm = tb; tb = nullptr; }
+        if (dm && dm->glv) dm = nullptr;                    // a GLV-split table has its own kernel (bp_capi_ipp.hip); here it is just "no table"
         int rc = tb ? msm_geom_table(g, C::Fr::BITS, tb->c, tb->W, sc2 ? 2 : 1, &ctx->tuning)
                     : msm_geom(g, C::Fr::BITS, n, ctx->c_override, sc2 ? 2 : 1, nnz, &ctx->tuning, ctx->win_count ? 0 : dm && dm->n == n ? kSmallDigitMax : kSmallMsmMax);
         if (rc) return rc;
@@ -843,9 +844,9 @@ int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_
     if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     const dim3 grid((unsigned)((n + 63) / 64));
     if (ctx->curve == BP_CURVE_BLS12_381)
-        hipLaunchKernelGGL(k_digit_table_build<Bls381>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bls381>*)points, (uint32_t)n, (XyzzPacked<Bls381>*)t->d);
+        hipLaunchKernelGGL(k_digit_table_build<Bls381>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bls381>*)points, (uint32_t)n, (XyzzPacked<Bls381>*)t->d, (uint32_t)rows);
     else
-        hipLaunchKernelGGL(k_digit_table_build<Bn254>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bn254>*)points, (uint32_t)n, (XyzzPacked<Bn254>*)t->d);
+        hipLaunchKernelGGL(k_digit_table_build<Bn254>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bn254>*)points, (uint32_t)n, (XyzzPacked<Bn254>*)t->d, (uint32_t)rows);
     if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     *out = t;
     return BP_OK;
@@ -1051,6 +1052,10 @@ int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
     case BP_TUNE_SMALL_MSM:
         if (value > 1) return BP_ERR_ARG;
         ctx->tuning.small_msm = value != 0;
+        return BP_OK;
+    case BP_TUNE_GLV:           // 0 automatic (on where the curve has the split: BLS12-381), 1 off
+        if (value > 1) return BP_ERR_ARG;
+        ctx->tuning.glv = value == 0;
         return BP_OK;
     case BP_TUNE_COMPACT_AT:    // 0 automatic, 1 never, else the live length (a power of two whose rounds are single launches) to compact at
         if (value > 1 && (value < 16 || (value & (value - 1)) || 2 * (size_t)value + 1 > kSmallDigitMax)) return BP_ERR_ARG;

@@ -35,6 +35,7 @@ struct bp_ipp_state {
     bp_g1table* table;       // window multiples of [G | H | Q] when G and H carry tables (bp_g1vec_precompute): every round's MSM is merged-window
     // generator compaction (bp_compact.cuh): once the live length has shrunk to compact_at the folded generators are materialised and
     // the remaining rounds run as single-launch rounds over THEIR digit multiples (n0, Pall, cG, cH, table then describe the compacted set)
+    bool glv;                // the compaction (and the rounds after it) work on GLV-split scalars (BLS12-381, no compaction tables, BP_TUNE_GLV)
     size_t compact_at;       // 0: this proof never compacts
     bool compacted;
     const bp_g1table *ctG, *ctH;   // compaction tables of G and H (bp_g1vec_precompute) when both have one: nothing to build, Horner chain of 60 doublings
@@ -223,11 +224,86 @@ struct Ipp {
         if (rc) return rc;
         if (!st->ev_side) HIPCHK(hipEventCreateWithFlags(&st->ev_side, hipEventDisableTiming));
         hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((npts + 63) / 64)), dim3(64), 0, side->stream, (const AffPacked<C>*)st->Pall, (uint32_t)npts,
-                           (XyzzPacked<C>*)tmp);
+                           (XyzzPacked<C>*)tmp, (uint32_t)rows);
         HIPCHK(hipGetLastError());
         rc = batch_to_affine(ctx, (const XyzzPacked<C>*)tmp, rows * npts, (AffPacked<C>*)st->Daff, side->stream, st);
         HIPCHK(hipEventRecord(st->ev_side, side->stream));
         st->side_pending = true;
+        return rc;
+    }
+
+    // ---- the same over GLV-split scalars (BLS12-381): 26 windows of 5 bits over 2 T sub-terms per output, a Horner chain of 125
+    // doublings, and a digit table of [G' | H' | Q] with 16 multiples of P and of phi(P) for k_small_msm_glv
+    static int compact_glv(bp_ipp_state* st) {
+        bp_ctx* ctx = st->ctx;
+        hipStream_t s = ctx->stream;
+        const size_t n0 = st->n0, nj = st->n, nout = 2 * nj, m = nout + 1, rows = kGlvRows;
+        int rc;
+        PoolBlock b_part, b_wsum, b_S, b_mx;
+        if (!b_part.alloc(ctx, (size_t)2 * kGlvCWin * nout * sizeof(XyzzPacked<C>)) || !b_wsum.alloc(ctx, (size_t)kGlvCWin * nout * sizeof(XyzzPacked<C>)) ||
+            !b_S.alloc(ctx, m * sizeof(XyzzPacked<C>)) || !b_mx.alloc(ctx, rows * m * sizeof(XyzzPacked<C>)))
+            return BP_ERR_DEVICE;
+        // c_G, c_H split into halves (sL / sR are free between rounds and large enough)
+        hipLaunchKernelGGL(k_glv_decompose<C>, dim3(blocks_for(n0)), dim3(kBlock), 0, s, (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, n0,
+                           (ScalarWords*)st->sL, (ScalarWords*)st->sR);
+        const AffPacked<C>* DG = (const AffPacked<C>*)st->Daff;
+        hipLaunchKernelGGL(k_compact_window_sums_glv<C>, dim3((unsigned)((nout + kBlock - 1) / kBlock), (unsigned)kGlvCWin, 2u), dim3(kBlock), 0, s, DG, DG + n0, 2 * n0,
+                           (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)n0, (uint32_t)nj, (uint32_t)nout, (XyzzPacked<C>*)b_part.p);
+        hipLaunchKernelGGL(k_compact_merge_halves<C>, dim3((unsigned)((nout + kBlock - 1) / kBlock), (unsigned)kGlvCWin), dim3(kBlock), 0, s, (const XyzzPacked<C>*)b_part.p,
+                           (uint32_t)nout, (uint32_t)nout, kGlvCWin, (XyzzPacked<C>*)b_wsum.p);
+        BP_TRACE_SYNC(ctx, "k_compact_window_sums_glv");
+        hipLaunchKernelGGL(k_compact_horner<C>, dim3((unsigned)((nout + kHornerQuads / 2 - 1) / (kHornerQuads / 2))), dim3(4 * kHornerQuads), 0, s,
+                           (const XyzzPacked<C>*)b_wsum.p, (uint32_t)nout, (uint32_t)nout, kGlvCWin, kGlvCBits, (const AffPacked<C>*)st->Q, (XyzzPacked<C>*)b_S.p);
+        BP_TRACE_SYNC(ctx, "k_compact_horner");
+        hipLaunchKernelGGL(k_digit_table_build_xyzz<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const XyzzPacked<C>*)b_S.p, (uint32_t)m, (uint32_t)rows,
+                           (XyzzPacked<C>*)b_mx.p);
+        HIPCHK(hipGetLastError());
+        bp_g1table* t = new (std::nothrow) bp_g1table();
+        if (!t) return BP_ERR_DEVICE;
+        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = kGlvBits; t->W = (int)rows; t->digits = true; t->affine = true; t->glv = true;
+        t->d = ctx->pool->get(rows * m * kPt, &t->cap);
+        if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+        if ((rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rows * m, (AffPacked<C>*)t->d, s, nullptr))) { bp_internal_table_free(t); return rc; }
+        hipLaunchKernelGGL(k_fr_fill_one, dim3(blocks_for(nj)), dim3(kBlock), 0, s, (ScalarWords*)st->cG, (ScalarWords*)st->cH, nj);
+        if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+        BP_TRACE_SYNC(ctx, "compaction (glv): digit table");
+        if (st->table) bp_internal_table_free(st->table);
+        st->table = t;
+        st->Pall = t->d;                 // the first m rows (multiple 1) are [G' | H' | Q] themselves
+        st->n0 = nj;
+        st->compacted = true;
+        return BP_OK;
+    }
+
+    // L, R of a round after a GLV compaction: the round's scalars are split in place, k_small_msm_glv leaves 26 x splits records per
+    // scalar set at bit positions 5 w, the host folds two tails of <= 125 doublings
+    static int msm2_glv(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
+        bp_ctx* ctx = st->ctx;
+        hipStream_t s = ctx->stream;
+        const size_t m = 2 * st->n0 + 1;
+        const unsigned splits = m > 512 ? 4u : 2u;                 // blocks per (window, set): half of them per scalar half
+        const int R1 = kGlvWin * (int)splits;
+        int rc;
+        bp_prof().lap(0);
+        if ((rc = ctx->window_sum.reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
+        if ((rc = host_pinned_reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
+        hipLaunchKernelGGL(k_glv_decompose<C>, dim3(blocks_for(m)), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, m, (ScalarWords*)st->sL,
+                           (ScalarWords*)st->sR);
+        hipLaunchKernelGGL(k_small_msm_glv<C>, dim3(kGlvWin, 2, splits), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)m,
+                           (const AffPacked<C>*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)2 * R1 * sizeof(XyzzPacked<C>), hipMemcpyDeviceToHost, s));
+        bp_prof().lap(1);
+        HIPCHK(hipStreamSynchronize(s));
+        bp_prof().lap(2);
+        uint16_t pos[kGlvWin * 4];
+        for (int r = 0; r < R1; r++) pos[r] = (uint16_t)(kGlvBits * (r / (int)splits));
+        const XyzzPacked<C>* rec = (const XyzzPacked<C>*)ctx->host_pinned;
+        const void* recs[2] = {rec, rec + R1};
+        const uint16_t* poss[2] = {pos, pos};
+        uint8_t* outs[2] = {L_le, R_le};
+        rc = bp_internal_fold_sets(ctx, 2, recs, 1, R1, poss, outs);
+        bp_prof().lap(3);
         return rc;
     }
 
@@ -241,6 +317,7 @@ struct Ipp {
         const bool tabled = st->ctG && st->ctH;
         if (!tabled && !st->Daff && (rc = build_original_multiples(st))) return rc;
         if (st->side_pending) { HIPCHK(hipStreamWaitEvent(s, st->ev_side, 0)); st->side_pending = false; }
+        if constexpr (C::HAS_GLV) { if (st->glv && !tabled) return compact_glv(st); }
         const int lgK = tabled ? 2 : 0;                                                  // tables: a scalar is 4 sub-scalars of 64 bits over the rows 2^(64 k) P
         const int nwin = ((C::Fr::BITS + 1 + kSmallDigitBits - 1) / kSmallDigitBits) >> lgK;      // 64 (16) windows of 4 bits
         const AffPacked<C>*DG, *DH;
@@ -261,16 +338,22 @@ struct Ipp {
                            (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, (uint32_t)n0, (uint32_t)nj, lgK, nwin, bias, (uint32_t)nout, (XyzzPacked<C>*)b_wsum.p);
         BP_TRACE_SYNC(ctx, "k_compact_window_sums");
         hipLaunchKernelGGL(k_compact_horner<C>, dim3((unsigned)((nout + kHornerQuads / 2 - 1) / (kHornerQuads / 2))), dim3(4 * kHornerQuads), 0, s,
-                           (const XyzzPacked<C>*)b_wsum.p, (uint32_t)nout, (uint32_t)nout, nwin, (const AffPacked<C>*)st->Q, (XyzzPacked<C>*)b_S.p);
+                           (const XyzzPacked<C>*)b_wsum.p, (uint32_t)nout, (uint32_t)nout, nwin, kSmallDigitBits, (const AffPacked<C>*)st->Q, (XyzzPacked<C>*)b_S.p);
         BP_TRACE_SYNC(ctx, "k_compact_horner");
-        hipLaunchKernelGGL(k_digit_table_build_xyzz<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const XyzzPacked<C>*)b_S.p, (uint32_t)m, (XyzzPacked<C>*)b_mx.p);
+        // the table of the rounds that follow: with the GLV split (BLS12-381) 16 multiples for k_small_msm_glv, else 8 for k_small_msm
+        bool glv_rounds = false;
+        if constexpr (C::HAS_GLV) glv_rounds = ctx->tuning.glv;
+        const size_t rrows = glv_rounds ? (size_t)kGlvRows : rows;
+        if (glv_rounds && !b_mx.alloc(ctx, rrows * m * sizeof(XyzzPacked<C>))) return BP_ERR_DEVICE;
+        hipLaunchKernelGGL(k_digit_table_build_xyzz<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const XyzzPacked<C>*)b_S.p, (uint32_t)m, (uint32_t)rrows, (XyzzPacked<C>*)b_mx.p);
         HIPCHK(hipGetLastError());
         bp_g1table* t = new (std::nothrow) bp_g1table();
         if (!t) return BP_ERR_DEVICE;
-        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = kSmallDigitBits; t->W = (int)rows; t->digits = true; t->affine = true;
-        t->d = ctx->pool->get(rows * m * kPt, &t->cap);
+        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = glv_rounds ? kGlvBits : kSmallDigitBits; t->W = (int)rrows; t->digits = true; t->affine = true;
+        t->glv = glv_rounds;
+        t->d = ctx->pool->get(rrows * m * kPt, &t->cap);
         if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
-        if ((rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rows * m, (AffPacked<C>*)t->d, s, nullptr))) { bp_internal_table_free(t); return rc; }
+        if ((rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rrows * m, (AffPacked<C>*)t->d, s, nullptr))) { bp_internal_table_free(t); return rc; }
         BP_TRACE_SYNC(ctx, "compaction: digit multiples");
         hipLaunchKernelGGL(k_fr_fill_one, dim3(blocks_for(nj)), dim3(kBlock), 0, s, (ScalarWords*)st->cG, (ScalarWords*)st->cH, nj);
         HIPCHK(hipGetLastError());
@@ -302,6 +385,7 @@ struct Ipp {
                                (const ScalarWords*)st->cH, cLR, st->n0, (size_t)0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR, 1);
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
+            if constexpr (C::HAS_GLV) { if (st->compacted && st->table && st->table->glv) return msm2_glv(st, L_le, R_le); }
             return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1, st->table);   // both sums in one pipeline pass
         }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
@@ -850,7 +934,7 @@ static int ctable_build_impl(bp_ctx* ctx, const bp_g1table* wt, bp_g1table** out
             bp_internal_table_free(t); return BP_ERR_DEVICE;
         }
     }
-    hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, (const AffPacked<C>*)gathered.p, (uint32_t)(K * n), (XyzzPacked<C>*)tmp.p);
+    hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((K * n + 63) / 64)), dim3(64), 0, s, (const AffPacked<C>*)gathered.p, (uint32_t)(K * n), (XyzzPacked<C>*)tmp.p, (uint32_t)rows);
     int rc = hipGetLastError() == hipSuccess ? Ipp<C>::batch_to_affine(ctx, (const XyzzPacked<C>*)tmp.p, rows * K * n, (AffPacked<C>*)t->d, s, nullptr) : BP_ERR_DEVICE;
     if (rc) { bp_internal_table_free(t); return rc; }
     *out = t;
@@ -1272,6 +1356,7 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
         if (cg && ch && cg->K == 4 && ch->K == 4 && og + n <= cg->n && oh + n <= ch->n && cg->device == ctx->device && ch->device == ctx->device) {
             st->ctG = cg; st->ctH = ch; st->ctG_off = og; st->ctH_off = oh;
         } else {
+            st->glv = ctx->tuning.glv && (ctx->curve == BP_CURVE_BLS12_381 ? Bls381::HAS_GLV : Bn254::HAS_GLV);
             rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::build_original_multiples(st) : Ipp<Bn254>::build_original_multiples(st);
             if (rc) { bp_ipp_state_free(st); return rc; }
         }

@@ -173,13 +173,13 @@ __global__ void __launch_bounds__(kBlock) k_bai_finish(const XyzzPacked<C>* __re
 // mult[(m - 1) * n + t] = m S_t, m = 1 .. 8, from packed lazy points (the compacted generators): seven dependent full additions per lane
 // through ONE addition site (it handles the empty accumulator and S + S).
 template <class C>
-__global__ void __launch_bounds__(64) k_digit_table_build_xyzz(const XyzzPacked<C>* __restrict__ S, uint32_t n, XyzzPacked<C>* __restrict__ mult) {
+__global__ void __launch_bounds__(64) k_digit_table_build_xyzz(const XyzzPacked<C>* __restrict__ S, uint32_t n, uint32_t rows, XyzzPacked<C>* __restrict__ mult) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const XyzzLazy<C> p = xyzz_lazy_unpack(S[t]);
     XyzzLazy<C> acc = xyzz_lazy_inf<C>();
 #pragma unroll 1
-    for (uint32_t m = 1; m <= (1u << (kSmallDigitBits - 1)); m++) {
+    for (uint32_t m = 1; m <= rows; m++) {
         acc = xyzz_lazy_add(acc, p);
         mult[(size_t)(m - 1) * n + t] = xyzz_lazy_pack(acc);
     }
@@ -270,7 +270,7 @@ __device__ __forceinline__ void quad_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <class C>
-__global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzPacked<C>* __restrict__ wsum, uint32_t nout, uint32_t pitch, int nwin,
+__global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzPacked<C>* __restrict__ wsum, uint32_t nout, uint32_t pitch, int nwin, int cw,
                                                                      const AffPacked<C>* __restrict__ extra, XyzzPacked<C>* __restrict__ out) {
     using Fp = typename C::Fp;
     constexpr int NW = Fp::NW;
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzP
 #pragma unroll 1
     for (int w = w_hi - 1; w >= w_lo; w--) {
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < cw; k++) {
             xyzz_lazy_dbl_quad<C>(lds, 2 * quad, q);
             quad_lds_fence();
         }
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzP
     }
     if (seg == 0) {
 #pragma unroll 1
-        for (int k = 0; k < 4 * h; k++) {                        // the upper half's weight 16^h
+        for (int k = 0; k < cw * h; k++) {                       // the upper half's weight 2^(cw h)
             xyzz_lazy_dbl_quad<C>(lds, 2 * quad, q);
             quad_lds_fence();
         }
@@ -318,6 +318,255 @@ __global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzP
     if (extra && blockIdx.x == 0 && threadIdx.x == 0) {
         const Aff<C> p = aff_unpack(*extra);
         out[nout] = xyzz_lazy_pack(xyzz_lazy_from_strict(xyzz_from_aff(p)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- GLV: half-length scalars (BLS12-381)
+// s P = s1 P + s2 phi(P) with s1, s2 < 2^128 (bp_curve.cuh: GLV_LAMBDA): everything that is a strictly serial chain over the bits of a
+// scalar halves -- the Horner chain of the compaction (252 -> 125 doublings) and the host tail of every round that follows (records
+// at bit positions < 130 instead of < 256) -- at the same number of additions: twice the terms, half the windows.
+// Decomposed scalars travel as ScalarWords: words 0..3 = s1, words 4..7 = s2.  Windows of the halves: kGlvWin = 26 windows of 5 bits
+// (130 bits) with the signed recoding of the pipeline, digit = window(k + bias) - 15 in [-15, 16]: 16 digit multiples per point (the
+// rounds after the compaction); the compaction itself: kGlvCWin = 33 windows of 4 bits over the SAME 8 multiples of the originals as
+// the plain form.
+constexpr int kGlvBits = 5, kGlvWin = 26, kGlvRows = 1 << (kGlvBits - 1);
+
+__device__ __forceinline__ void mul64x64(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) { lo = a * b; hi = __umul64hi(a, b); }
+// acc (3 words) += a * b at word offset 0 (carry into the upper words)
+__device__ __forceinline__ void mac192(uint64_t (&acc)[3], uint64_t a, uint64_t b) {
+    uint64_t lo, hi;
+    mul64x64(a, b, lo, hi);
+    acc[0] += lo; hi += acc[0] < lo;
+    acc[1] += hi; acc[2] += acc[1] < hi;
+}
+
+// s (canonical, < r) -> s1 = s mod LAMBDA, s2 = floor(s / LAMBDA): Barrett with m = 2^128 + MLO = floor(2^256 / LAMBDA)
+//   q' = floor((s + floor(s MLO / 2^128)) / 2^128) is q or q - 1 (exhaustively at the boundaries + 2e5 random values, Python integers)
+template <class C>
+__device__ __forceinline__ void glv_decompose(const ScalarWords& sw, uint64_t (&s1)[2], uint64_t (&s2)[2]) {
+    const uint64_t s[4] = {sw.w[0] | ((uint64_t)sw.w[1] << 32), sw.w[2] | ((uint64_t)sw.w[3] << 32), sw.w[4] | ((uint64_t)sw.w[5] << 32),
+                           sw.w[6] | ((uint64_t)sw.w[7] << 32)};
+    const uint64_t m0 = C::GLV_MLO[0], m1 = C::GLV_MLO[1], l0 = C::GLV_LAMBDA[0], l1 = C::GLV_LAMBDA[1];
+    // t = (s * MLO) >> 128: columns of the 4 x 2 word product, three-word running accumulator
+    uint64_t acc[3] = {0, 0, 0}, t[4];
+    mac192(acc, s[0], m0);                                   // column 0
+    acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[0], m1); mac192(acc, s[1], m0);            // column 1
+    acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[1], m1); mac192(acc, s[2], m0);            // column 2 -> t[0]
+    t[0] = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[2], m1); mac192(acc, s[3], m0);            // column 3 -> t[1]
+    t[1] = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[3], m1);                                   // column 4 -> t[2], t[3]
+    t[2] = acc[0]; t[3] = acc[1];
+    // u = s + t (< 2^256); q = u >> 128
+    uint64_t u[4], cy = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const uint64_t a = s[i] + t[i], b = a + cy; cy = (uint64_t)(a < s[i]) + (uint64_t)(b < a); u[i] = b; }
+    uint64_t q0 = u[2], q1 = u[3];
+    // rem = s - q * LAMBDA (fits three words with room: < 2 LAMBDA)
+    uint64_t p[3] = {0, 0, 0};
+    mac192(p, q0, l0);
+    { uint64_t hi[3] = {0, 0, 0}; mac192(hi, q0, l1); mac192(hi, q1, l0); p[1] += hi[0]; p[2] += hi[1] + (p[1] < hi[0]); }
+    p[2] += q1 * l1;
+    uint64_t r0 = s[0] - p[0], b0 = s[0] < p[0];
+    uint64_t r1 = s[1] - p[1] - b0, b1 = (s[1] < p[1]) || (s[1] == p[1] && b0);
+    uint64_t r2 = s[2] - p[2] - b1;
+    // one conditional correction: rem >= LAMBDA  <=>  r2 != 0 or (r1, r0) >= (l1, l0)
+    const bool ge = r2 != 0 || r1 > l1 || (r1 == l1 && r0 >= l0);
+    if (ge) {
+        const uint64_t n0 = r0 - l0, bb = r0 < l0;
+        r1 = r1 - l1 - bb; r0 = n0;
+        q0 += 1; q1 += q0 == 0;
+    }
+    s1[0] = r0; s1[1] = r1; s2[0] = q0; s2[1] = q1;
+}
+
+// out1[i] = split(in1[i]), out2[i] = split(in2[i]) (in place allowed); in2 == nullptr: one vector
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_glv_decompose(const ScalarWords* in1, const ScalarWords* in2, size_t n, ScalarWords* out1, ScalarWords* out2) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll 1
+    for (int v = 0; v < (in2 ? 2 : 1); v++) {
+        uint64_t a[2], b[2];
+        glv_decompose<C>((v ? in2 : in1)[i], a, b);
+        ScalarWords o;
+        o.w[0] = (uint32_t)a[0]; o.w[1] = (uint32_t)(a[0] >> 32); o.w[2] = (uint32_t)a[1]; o.w[3] = (uint32_t)(a[1] >> 32);
+        o.w[4] = (uint32_t)b[0]; o.w[5] = (uint32_t)(b[0] >> 32); o.w[6] = (uint32_t)b[1]; o.w[7] = (uint32_t)(b[1] >> 32);
+        (v ? out2 : out1)[i] = o;
+    }
+}
+
+// signed BITS-bit digit w of a 128-bit half (lo, hi): window w of (half + bias), bias = sum_w (2^(BITS-1) - 1) 2^(BITS w) over NWIN windows
+// (NWIN * BITS >= 130 bits, so the sum never overflows its windows); in [-(2^(BITS-1) - 1), 2^(BITS-1)].  w is wave-uniform.
+template <int BITS, int NWIN>
+__device__ __forceinline__ int glv_digit(uint64_t lo, uint64_t hi, int w) {
+    static_assert(BITS * NWIN >= 130 && BITS * NWIN <= 192, "three words");
+    constexpr uint64_t half1 = (1u << (BITS - 1)) - 1;
+    // bias words at compile time
+    uint64_t b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+    for (int i = 0; i < NWIN; i++) {
+        const int off = BITS * i;
+        if (off < 64) { b0 |= half1 << off; if (off + BITS > 64) b1 |= half1 >> (64 - off); }
+        else if (off < 128) { b1 |= half1 << (off - 64); if (off + BITS > 128) b2 |= half1 >> (128 - off); }
+        else b2 |= half1 << (off - 128);
+    }
+    uint64_t k[3];
+    k[0] = lo + b0;
+    const uint64_t c0 = k[0] < lo;
+    const uint64_t a1 = hi + b1;
+    k[1] = a1 + c0;
+    k[2] = b2 + (uint64_t)(a1 < hi) + (uint64_t)(k[1] < a1);
+    const int off = BITS * w, word = off >> 6, sh = off & 63;
+    const uint64_t x = word == 0 ? k[0] : word == 1 ? k[1] : k[2], y = word == 0 ? k[1] : word == 1 ? k[2] : 0;
+    const uint64_t v = sh ? (x >> sh) | (y << (64 - sh)) : x;
+    return (int)(v & ((1u << BITS) - 1)) - (int)half1;
+}
+// the 128-bit half `kind` of a decomposed scalar, one 16-byte load (kind is block-uniform everywhere: no per-lane selection)
+__device__ __forceinline__ void glv_half(const ScalarWords* sc, size_t i, int kind, uint64_t& lo, uint64_t& hi) {
+    const uint4 h = reinterpret_cast<const uint4*>(sc + i)[kind];
+    lo = h.x | ((uint64_t)h.y << 32);
+    hi = h.z | ((uint64_t)h.w << 32);
+}
+
+template <class C> __device__ __forceinline__ Fe<typename C::Fp> glv_beta_mont() { return fe_to_mont<typename C::Fp>(fe_unpack_words<typename C::Fp>(C::BETA)); }
+// phi of a lazy XYZZ point: (BETA X, Y, ZZ, ZZZ) -- phi is a group homomorphism, so it is applied ONCE to a finished partial sum of
+// phi-side terms instead of to every term
+template <class C> __device__ __forceinline__ void xyzz_lazy_phi(XyzzLazy<C>& a) {
+    using Fp = typename C::Fp;
+    if (a.inf) return;
+    a.x = feb_widen<8>(feb_mul(a.x, feb_from_strict<Fp>(glv_beta_mont<C>())));
+}
+
+// Window sums of the compaction over HALF-LENGTH scalars: lane (o, w, kind) -- output o, window w of the kGlvCWin 4-bit windows of a
+// half, kind 0: the s1 halves over P, kind 1: the s2 halves over the same rows of D, with phi applied to the finished sum --
+//     part[(kind * kGlvCWin + w) * pitch + o] = [phi] sum_t digit_w(half_kind(c_t)) P_t           (T mixed additions per lane)
+// D as in k_compact_window_sums (8 multiples, K = 1); cG / cH arrive DECOMPOSED (k_glv_decompose).  k_compact_merge_halves adds the
+// two parts of every (o, w).
+constexpr int kGlvCBits = 4, kGlvCWin = 33;
+template <class C>
+__global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums_glv(const AffPacked<C>* __restrict__ DG, const AffPacked<C>* __restrict__ DH, size_t drows,
+                                                                       const ScalarWords* __restrict__ cG, const ScalarWords* __restrict__ cH, uint32_t n0, uint32_t nj,
+                                                                       uint32_t pitch, XyzzPacked<C>* __restrict__ part) {
+    using Fp = typename C::Fp;
+    const uint32_t o = blockIdx.x * kBlock + threadIdx.x, w = blockIdx.y, kind = blockIdx.z;
+    if (o >= 2 * nj) return;
+    const uint32_t vec = o >= nj ? 1u : 0u, j = o - vec * nj;
+    const ScalarWords* sc = vec ? cH : cG;
+    const AffPacked<C>* D = vec ? DH : DG;
+    const uint32_t terms = n0 / nj;
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+    uint32_t e = 0;
+    auto fetch = [&](uint32_t t, Aff<C>& p, bool& neg) -> bool {
+        uint64_t lo, hi;
+        glv_half(sc, j + (size_t)t * nj, (int)kind, lo, hi);
+        const int d = glv_digit<kGlvCBits, kGlvCWin>(lo, hi, (int)w);
+        if (d == 0) return false;
+        p = aff_unpack(D[(size_t)((d < 0 ? -d : d) - 1) * drows + j + (size_t)t * nj]);
+        neg = d < 0;
+        return !aff_is_inf(p);
+    };
+    auto restart = [&]() {
+        Aff<C> p; bool neg;
+        while (e < terms && !fetch(e, p, neg)) e++;
+        if (e < terms) {
+            if (neg) p.y = fe_neg(p.y);
+            acc = xyzz_lazy_from_strict(xyzz_from_aff(p));
+            e++;
+        }
+    };
+    restart();
+    while (e < terms) {
+        while (e < terms) {
+            Aff<C> p; bool neg;
+            if (!fetch(e, p, neg)) { e++; continue; }
+            FeB<Fp, 2> qy = feb_widen<2>(feb_from_strict<Fp>(p.y));
+            if (neg) qy = feb_neg_canonical<Fp>(p.y);
+            if (!xyzz_lazy_add_aff_fast(acc, feb_from_strict<Fp>(p.x), qy)) break;
+            e++;
+        }
+        if (e < terms) {
+            Aff<C> p; bool neg;
+            if (fetch(e, p, neg)) {
+                if (neg) p.y = fe_neg(p.y);
+                xyzz_lazy_add_aff(acc, p);
+            }
+            e++;
+            if (acc.inf) restart();
+        }
+    }
+    if (kind) xyzz_lazy_phi<C>(acc);
+    part[((size_t)kind * kGlvCWin + w) * pitch + o] = xyzz_lazy_pack(acc);
+}
+
+// wsum[w * pitch + o] = part[w * pitch + o] + part[(nwin + w) * pitch + o]     (one full addition per lane)
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_compact_merge_halves(const XyzzPacked<C>* __restrict__ part, uint32_t nout, uint32_t pitch, int nwin, XyzzPacked<C>* __restrict__ wsum) {
+    const uint32_t o = blockIdx.x * kBlock + threadIdx.x, w = blockIdx.y;
+    if (o >= nout) return;
+    const XyzzLazy<C> a = xyzz_lazy_unpack(part[(size_t)w * pitch + o]), b = xyzz_lazy_unpack(part[((size_t)nwin + w) * pitch + o]);
+    wsum[(size_t)w * pitch + o] = xyzz_lazy_pack(xyzz_lazy_add(a, b));
+}
+
+// One round of the inner-product argument over a compacted, GLV-split generator set: block (w, set, z) with z = (split, kind) sums the
+// digit-w terms of its share of the n terms for ONE half of the scalars (kind = z & 1) -- the digit's multiple is LOADED from
+// mult[(m - 1) * n + t] = m P_t (affine, 16 multiples) for both kinds; phi is applied once to the block's finished sum of a kind-1 block --
+// and leaves one record at bit position 5 w: window_sum[(set * kGlvWin + w) * gridDim.z + z].  sc1 / sc2: the round's two scalar sets,
+// decomposed.  gridDim.z is even.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_small_msm_glv(const ScalarWords* __restrict__ sc1, const ScalarWords* __restrict__ sc2, uint32_t n,
+                                                          const AffPacked<C>* __restrict__ mult, XyzzPacked<C>* __restrict__ window_sum) {
+    using Fp = typename C::Fp;
+    __shared__ XyzzPacked<C> lds[kBlock];
+    const int w = blockIdx.x, set = blockIdx.y, kind = blockIdx.z & 1;
+    const ScalarWords* sc = set ? sc2 : sc1;
+    const uint32_t stride = kBlock * (gridDim.z >> 1);
+    uint32_t t = (blockIdx.z >> 1) * kBlock + threadIdx.x;
+    XyzzLazy<C> mine = xyzz_lazy_inf<C>();
+    auto fetch = [&](uint32_t tt, Aff<C>& p, bool& neg) -> bool {
+        uint64_t lo, hi;
+        glv_half(sc, tt, kind, lo, hi);
+        const int d = glv_digit<kGlvBits, kGlvWin>(lo, hi, w);
+        if (d == 0) return false;
+        p = aff_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n + tt]);
+        neg = d < 0;
+        return !aff_is_inf(p);
+    };
+    auto restart = [&]() {
+        Aff<C> p; bool neg;
+        while (t < n && !fetch(t, p, neg)) t += stride;
+        if (t < n) {
+            if (neg) p.y = fe_neg(p.y);
+            mine = xyzz_lazy_from_strict(xyzz_from_aff(p));
+            t += stride;
+        }
+    };
+    restart();
+    while (t < n) {
+        while (t < n) {
+            Aff<C> p; bool neg;
+            if (!fetch(t, p, neg)) { t += stride; continue; }
+            FeB<Fp, 2> qy = feb_widen<2>(feb_from_strict<Fp>(p.y));
+            if (neg) qy = feb_neg_canonical<Fp>(p.y);
+            if (!xyzz_lazy_add_aff_fast(mine, feb_from_strict<Fp>(p.x), qy)) break;
+            t += stride;
+        }
+        if (t < n) {
+            Aff<C> p; bool neg;
+            if (fetch(t, p, neg)) {
+                if (neg) p.y = fe_neg(p.y);
+                xyzz_lazy_add_aff(mine, p);
+            }
+            t += stride;
+            if (mine.inf) restart();
+        }
+    }
+    mine = block_tree_sum_quad<C>(mine, lds, kBlock);
+    if (threadIdx.x == 0) {
+        if (kind) xyzz_lazy_phi<C>(mine);
+        window_sum[((size_t)set * kGlvWin + w) * gridDim.z + blockIdx.z] = xyzz_lazy_pack(mine);
     }
 }
 

@@ -31,6 +31,15 @@ struct Bls381 {
                                         0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
     static constexpr uint32_t GY[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
                                         0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+    // GLV endomorphism (round 4; bp_compact.cuh): phi(x, y) = (BETA x, y) = LAMBDA (x, y) on G1, LAMBDA = z^2 - 1 for the BLS parameter
+    // z = -0xd201000000010000 (LAMBDA^2 + LAMBDA + 1 = r; checked with Python integers, and by every parity test that crosses the
+    // compaction).  A scalar s < r splits as s = s1 + s2 LAMBDA by plain division: s1 < LAMBDA < 2^128, s2 <= r / LAMBDA < 2^128.
+    // GLV_MLO = floor(2^256 / LAMBDA) - 2^128 (Barrett quotient, at most one correction).
+    static constexpr bool HAS_GLV = true;
+    static constexpr uint32_t BETA[12] = {0x0000aaacu, 0x8bfd0000u, 0x4f49fffdu, 0x409427ebu, 0x0fb85f9bu, 0x897d2965u,
+                                          0x89759ad4u, 0xaa0d857du, 0x63d4de85u, 0xec024086u, 0x397fe699u, 0x1a0111eau};
+    static constexpr uint64_t GLV_LAMBDA[2] = {0x00000000ffffffffull, 0xac45a4010001a402ull};
+    static constexpr uint64_t GLV_MLO[2] = {0x63f6e522f6cfee30ull, 0x7c6becf1e01faaddull};
 };
 
 struct Bn254 {
@@ -43,6 +52,12 @@ struct Bn254 {
     static constexpr uint32_t COFACTOR[4] = {1, 0, 0, 0};
     static constexpr uint32_t GX[8] = {0x00000012u, 0xa7000000u, 0x00000013u, 0x61210000u, 0x00000008u, 0xba344d80u, 0x40000001u, 0x25236482u};
     static constexpr uint32_t GY[8] = {0x00000001u, 0, 0, 0, 0, 0, 0, 0};
+    // (the Nogami curve's lambda has 192 bits: a balanced split needs a lattice reduction with signed halves -- not built; the GLV
+    // paths of bp_compact.cuh are compiled for BLS12-381 only)
+    static constexpr bool HAS_GLV = false;
+    static constexpr uint32_t BETA[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr uint64_t GLV_LAMBDA[2] = {1, 0};
+    static constexpr uint64_t GLV_MLO[2] = {0, 0};
 };
 
 template <class C>

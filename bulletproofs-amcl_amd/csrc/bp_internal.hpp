@@ -124,6 +124,7 @@ struct bp_tuning {
     uint64_t task_target = 0;   // task count the accumulate aims at: [1024, 2^28]
     bool small_msm = true;      // single-launch path for n <= 512
     uint32_t compact_at = 0;    // inner-product prover: live length at which the folded generators are materialised (0 automatic, 1 never)
+    bool glv = true;            // ... and whether that compaction (and the rounds after it) split the scalars with the GLV endomorphism (BLS12-381)
 };
 
 struct bp_ctx {
@@ -236,6 +237,8 @@ struct bp_g1table {
     // round is <= kSmallMsmMax terms: the lanes then load their digit's multiple instead of computing it (library-internal).
     bool digits = false;
     bool affine = false;     // digits only: the rows are canonical AFFINE points (AffPacked) instead of lazy XYZZ (bp_compact.cuh: batch conversion)
+    bool glv = false;        // digits only: the table of a GLV-split set (bp_compact.cuh: k_glv_table_rows; rows[((m - 1) * 2 + half) * n + t], 16 multiples):
+                             // only k_small_msm_glv reads it; the generic MSM paths ignore such a table
     int K = 1;               // digits only: sub-rows per point (compaction table: K = 4, rows[(m - 1) * K * n + k * n + i] = m 2^(64 k) P_i)
 };
 extern "C" void bp_internal_table_free(bp_g1table* t);

@@ -854,13 +854,14 @@ __device__ __forceinline__ uint32_t window_bits(const uint64_t (&q)[4], int off,
 // then LOADS its term -- no doubling / mixed-addition bodies are executed (or fetched) at all, the kernel is its tree.
 constexpr int kSmallDigitBits = 4;     // the window width of the small path (msm_geom): |digit| <= 8
 template <class C>
-__global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>* __restrict__ pts, uint32_t n, XyzzPacked<C>* __restrict__ mult) {
+__global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>* __restrict__ pts, uint32_t n, XyzzPacked<C>* __restrict__ mult,
+                                                              uint32_t rows = 1u << (kSmallDigitBits - 1)) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const Aff<C> p = aff_unpack(pts[t]);
     XyzzLazy<C> acc = xyzz_lazy_inf<C>();
 #pragma unroll 1
-    for (uint32_t m = 1; m <= (1u << (kSmallDigitBits - 1)); m++) {       // one addition body: it handles the empty accumulator and P + P
+    for (uint32_t m = 1; m <= rows; m++) {       // one addition body: it handles the empty accumulator and P + P
         xyzz_lazy_add_aff(acc, p);
         mult[(size_t)(m - 1) * n + t] = xyzz_lazy_pack(acc);
     }

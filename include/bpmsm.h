@@ -94,6 +94,9 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 1536 terms (and, inside an inner-product proof of 16 .. 4096
                                * generators, for its rounds of up to 8193 terms over precomputed digit multiples) */
 #define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
+#define BP_TUNE_GLV 7         /* 0 (default): that compaction and the rounds after it split every scalar into two 128-bit halves with the curve's
+                               * endomorphism where this build has it (BLS12-381: half the Horner chain, half the host tail); 1 = off.  Proof bytes
+                               * do not depend on it. */
 #define BP_TUNE_COMPACT_AT 6  /* inner-product prover (bp_ipp_create, round API): live length at which the folded generators are materialised once
                                * and the remaining rounds run as single launches over their digit multiples, instead of a full-size paired MSM in
                                * every round (/root/reference src/ipp.rs:181-188 folds G, H every round; this is that fold, done once).  0 = automatic

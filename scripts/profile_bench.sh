@@ -4,7 +4,7 @@
 #     scripts/profile_bench.sh r03
 # writes gpurun_out/<tag>_bench_n1_{kernel_stats.csv,under_rocprof.json,pmc_hbm.json,pmc_sq.json}; copy them to profiles/.
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out
@@ -19,6 +19,7 @@ d=$out/prof_${tag}_trace; rm -rf "$d"; mkdir -p "$d"
 # sample the clocks WHILE the bench runs (after it, sclk has already dropped): a background loop on this shell, stopped by its PID
 ( while true; do { date -u +"%H:%M:%S.%N UTC  during the kernel-trace run"; rocm-smi --showclocks --showpower 2>&1 | grep "sclk\|mclk\|Power"; } >> "$out/${tag}_bench_n1_rocm_smi.txt"; sleep 0.3; done ) &
 sampler=$!
+trap 'kill $sampler 2>/dev/null || true' EXIT      # the script runs under set -e: a failing profiler run must not leave the sampler polling rocm-smi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python3 "$root/bench.py" $args --steps 60 > "$out/${tag}_bench_n1_under_rocprof.json" 2> "$d/stderr.log"
 kill $sampler 2>/dev/null || true
 wait $sampler 2>/dev/null || true

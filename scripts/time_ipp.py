@@ -29,6 +29,8 @@ def main():
         ctx.set_tuning(bp.TUNE_TAIL_CHAINS, int(os.environ["TIME_IPP_CHAINS"]))
     if os.environ.get("TIME_IPP_TASK_TARGET"):
         ctx.set_tuning(bp.TUNE_TASK_TARGET, int(os.environ["TIME_IPP_TASK_TARGET"]))
+    if os.environ.get("TIME_IPP_NO_GLV"):
+        ctx.set_tuning(bp.TUNE_GLV, 1)
     if os.environ.get("TIME_IPP_COMPACT_AT"):
         ctx.set_tuning(bp.TUNE_COMPACT_AT, int(os.environ["TIME_IPP_COMPACT_AT"]))     # 1 = never compact the generators
     for lg in lgs:

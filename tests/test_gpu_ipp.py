@@ -251,6 +251,9 @@ def test_ipp_generator_compaction_vs_oracle(bp, ctxs, name, n, at, unit_gf):
         plain = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
         ctx.set_tuning(bp.TUNE_COMPACT_AT, at)
         proof = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        ctx.set_tuning(bp.TUNE_GLV, 1)                    # without the GLV split of the scalars (the only form BN254 has)
+        noglv = bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b)
+        ctx.set_tuning(bp.TUNE_GLV, 0)
         st = bp.IPPState(ctx, Gv, Hv, Q, Gf, Hf, a, b)    # the same through bp_ipp_round / bp_ipp_fold with the caller's transcript
         tr = bp.Transcript(b"innerproduct")
         tr.append_message(b"dom-sep", b"ipp v1")
@@ -265,8 +268,10 @@ def test_ipp_generator_compaction_vs_oracle(bp, ctxs, name, n, at, unit_gf):
         fa, fb = st.finish()
     finally:
         ctx.set_tuning(bp.TUNE_COMPACT_AT, 0)
+        ctx.set_tuning(bp.TUNE_GLV, 0)
     assert (plain.L, plain.R, plain.a, plain.b) == want
     assert (proof.L, proof.R, proof.a, proof.b) == want
+    assert (noglv.L, noglv.R, noglv.a, noglv.b) == want
     assert (Ls, Rs, fa, fb) == want
     # ... and over the vectors' COMPACTION TABLES (bp_g1vec_precompute with a width that divides 64: rows 2^(64 k) P, Horner chain of 60 doublings)
     try:
