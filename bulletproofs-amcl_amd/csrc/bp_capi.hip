@@ -290,9 +290,12 @@ struct Impl {
             const void* mult = dm && dm->n == n && g.c <= dm->c ? dm->d : nullptr;
             const dim3 grid(W, g.small_blocks);
             auto* ws = (XyzzPacked<C>*)ctx->window_sum.p;
-            if (!mult) hipLaunchKernelGGL((k_small_msm<C, 0>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult);
-            else if (dm->affine) hipLaunchKernelGGL((k_small_msm<C, 2>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult);
-            else hipLaunchKernelGGL((k_small_msm<C, 1>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult);
+            // an inner-product round (ctx->ipp_live set by bp_capi_ipp.hip around this call): only the terms that can be non-zero
+            IppSparse sp = {0, 0, 0};
+            if (ctx->ipp_live >= 2 && sc2 && n == 2 * (size_t)ctx->ipp_n0 + 1) sp = IppSparse{ctx->ipp_n0, ctx->ipp_live, ctx->ipp_live / 2};
+            if (!mult) hipLaunchKernelGGL((k_small_msm<C, 0>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult, sp);
+            else if (dm->affine) hipLaunchKernelGGL((k_small_msm<C, 2>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult, sp);
+            else hipLaunchKernelGGL((k_small_msm<C, 1>), grid, dim3(kBlock), 0, st, pts, sc, sc2, (uint32_t)n, tab, ws, mult, sp);
             BP_TRACE_SYNC(ctx, "k_small_msm<C>");
             if (tm) HIPCHK(hipEventRecord(ctx->ev[6], st));
             HIPCHK(hipGetLastError());

@@ -281,7 +281,7 @@ struct Ipp {
         bp_ctx* ctx = st->ctx;
         hipStream_t s = ctx->stream;
         const size_t m = 2 * st->n0 + 1;
-        const unsigned splits = m > 512 ? 4u : 2u;                 // blocks per (window, set): half of them per scalar half
+        const unsigned splits = st->n0 + 1 > 512 ? 4u : 2u;         // blocks per (window, set): half of them per scalar half (n0 + 1 participating terms)
         const int R1 = kGlvWin * (int)splits;
         int rc;
         bp_prof().lap(0);
@@ -289,8 +289,9 @@ struct Ipp {
         if ((rc = host_pinned_reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
         hipLaunchKernelGGL(k_glv_decompose<C>, dim3(blocks_for(m)), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, m, (ScalarWords*)st->sL,
                            (ScalarWords*)st->sR);
+        const IppSparse sp = st->n >= 2 ? IppSparse{(uint32_t)st->n0, (uint32_t)st->n, (uint32_t)(st->n / 2)} : IppSparse{0, 0, 0};
         hipLaunchKernelGGL(k_small_msm_glv<C>, dim3(kGlvWin, 2, splits), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)m,
-                           (const AffPacked<C>*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p);
+                           (const AffPacked<C>*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p, sp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)2 * R1 * sizeof(XyzzPacked<C>), hipMemcpyDeviceToHost, s));
         bp_prof().lap(1);
@@ -386,7 +387,10 @@ struct Ipp {
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
             if constexpr (C::HAS_GLV) { if (st->compacted && st->table && st->table->glv) return msm2_glv(st, L_le, R_le); }
-            return bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1, st->table);   // both sums in one pipeline pass
+            ctx->ipp_n0 = (uint32_t)st->n0; ctx->ipp_live = (uint32_t)st->n;       // single-launch rounds walk the participating terms only
+            const int rcm = bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1, st->table);   // both sums in one pipeline pass
+            ctx->ipp_n0 = 0; ctx->ipp_live = 0;
+            return rcm;
         }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
                            (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,

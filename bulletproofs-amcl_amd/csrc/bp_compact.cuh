@@ -516,21 +516,23 @@ __global__ void __launch_bounds__(kBlock) k_compact_merge_halves(const XyzzPacke
 // and leaves one record at bit position 5 w: window_sum[(set * kGlvWin + w) * gridDim.z + z].  sc1 / sc2: the round's two scalar sets,
 // decomposed.  gridDim.z is even.
 template <class C>
-__global__ void __launch_bounds__(kBlock) k_small_msm_glv(const ScalarWords* __restrict__ sc1, const ScalarWords* __restrict__ sc2, uint32_t n,
-                                                          const AffPacked<C>* __restrict__ mult, XyzzPacked<C>* __restrict__ window_sum) {
+__global__ void __launch_bounds__(kBlock) k_small_msm_glv(const ScalarWords* __restrict__ sc1, const ScalarWords* __restrict__ sc2, uint32_t n_all,
+                                                          const AffPacked<C>* __restrict__ mult, XyzzPacked<C>* __restrict__ window_sum, IppSparse sp) {
     using Fp = typename C::Fp;
     __shared__ XyzzPacked<C> lds[kBlock];
     const int w = blockIdx.x, set = blockIdx.y, kind = blockIdx.z & 1;
     const ScalarWords* sc = set ? sc2 : sc1;
     const uint32_t stride = kBlock * (gridDim.z >> 1);
+    const uint32_t n = sp.live ? sp.n0 + 1 : n_all;             // the lanes walk the terms that can be non-zero (IppSparse, bp_kernels.cuh)
     uint32_t t = (blockIdx.z >> 1) * kBlock + threadIdx.x;
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
-    auto fetch = [&](uint32_t tt, Aff<C>& p, bool& neg) -> bool {
+    auto fetch = [&](uint32_t e, Aff<C>& p, bool& neg) -> bool {
+        const uint32_t tt = ipp_term(sp, set, e);
         uint64_t lo, hi;
         glv_half(sc, tt, kind, lo, hi);
         const int d = glv_digit<kGlvBits, kGlvWin>(lo, hi, w);
         if (d == 0) return false;
-        p = aff_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n + tt]);
+        p = aff_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n_all + tt]);
         neg = d < 0;
         return !aff_is_inf(p);
     };

@@ -133,6 +133,7 @@ struct bp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int c_override = 0;
+    uint32_t ipp_n0 = 0, ipp_live = 0;   // set around the paired MSM of an inner-product round: generators per vector and the round's live length (IppSparse)
     int win_first = 0, win_count = 0;   // window group of the MSM being queued (bp_msm_g1_windows_subset sets and clears them); 0 = all windows
     bp_tuning tuning;
     bool timing = false;

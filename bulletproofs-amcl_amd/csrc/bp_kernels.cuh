@@ -867,6 +867,20 @@ __global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>
     }
 }
 
+// The terms of an inner-product round that CAN be non-zero.  A round's scalar set over [G (n0) | H (n0) | Q] is zero on half of the
+// generators by construction (bp_ipp.cuh: L takes the G_k with k mod live >= h and the H_k with k mod live < h, R the other halves),
+// so a lane that walks all 2 n0 + 1 terms spends half of its serial steps skipping zeros -- whole waves at a time in the first
+// rounds, lane by lane (i.e. at the full price of an addition) once h < 64.  With live != 0 the lanes enumerate the n0 + 1
+// participating terms instead: e < n0 + 1 -> term index.  live = 0: identity (a plain MSM).
+struct IppSparse { uint32_t n0, live, h; };
+__device__ __forceinline__ uint32_t ipp_term(const IppSparse& sp, int set, uint32_t e) {
+    if (sp.live == 0) return e;
+    if (e >= sp.n0) return 2 * sp.n0;                                   // Q
+    const uint32_t half = e >= sp.n0 / 2 ? 1u : 0u, j = e - half * (sp.n0 / 2), blk = j / sp.h, o = j - blk * sp.h;
+    const bool upper = (set == 0) == (half == 0);                       // L: G upper, H lower;  R: G lower, H upper
+    return half * sp.n0 + blk * sp.live + (upper ? sp.h : 0u) + o;
+}
+
 // MODE (round 4: one body per way of obtaining a term -- with all three in one kernel the BN254 instantiation needed 512 VGPRs + 256
 // AGPRs and still spilled 153 registers): 0 = the lane multiplies its point by the digit (doubling chain); 1 = it loads
 // the digit's multiple from `mult` as a packed lazy XYZZ point, full addition; 2 = `mult` holds AFFINE rows (AffPacked, canonical:
@@ -874,10 +888,11 @@ __global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>
 template <class C, int MODE>
 __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __restrict__ pts, const ScalarWords* __restrict__ sc1,
                                                       const ScalarWords* __restrict__ sc2, uint32_t n, WinTab tab,
-                                                      XyzzPacked<C>* __restrict__ window_sum, const void* __restrict__ mult) {
+                                                      XyzzPacked<C>* __restrict__ window_sum, const void* __restrict__ mult, IppSparse sp) {
     __shared__ XyzzPacked<C> lds[kBlock];
     const int w = blockIdx.x, wps = tab.W / tab.nsets, set = w / wps;
     const int cw = tab.cw[w], off = tab.off[w];
+    const uint32_t ne = sp.live ? sp.n0 + 1 : n;                        // terms this block's lanes walk (see IppSparse)
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
     // grid.y blocks share a window's terms (block b: terms b * 256 + lane, stride 256 * grid.y) and leave one record each
     if (MODE == 2) {
@@ -887,12 +902,15 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         using Fp = typename C::Fp;
         const uint32_t stride = kBlock * gridDim.y;
         uint32_t t = blockIdx.y * kBlock + threadIdx.x;
-        auto fetch = [&](uint32_t tt, Aff<C>& p, bool& neg) -> bool {
+        const uint32_t n_all = n;
+        n = ne;                                                         // the loops below run over the enumeration; fetch maps it to the term
+        auto fetch = [&](uint32_t e, Aff<C>& p, bool& neg) -> bool {
+            const uint32_t tt = ipp_term(sp, set, e);
             uint64_t q[4];
             add256(q, (set ? sc2 : sc1)[tt], tab.bias);
             const int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
             if (d == 0) return false;
-            p = aff_unpack(((const AffPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n + tt]);
+            p = aff_unpack(((const AffPacked<C>*)mult)[(size_t)((d < 0 ? -d : d) - 1) * n_all + tt]);
             neg = d < 0;
             return !aff_is_inf(p);
         };
@@ -927,7 +945,8 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         }
     } else {
 #pragma unroll 1
-    for (uint32_t t = blockIdx.y * kBlock + threadIdx.x; t < n; t += kBlock * gridDim.y) {      // kSmallMsmMax / kBlock terms per lane at most (16 with mult)
+    for (uint32_t e = blockIdx.y * kBlock + threadIdx.x; e < ne; e += kBlock * gridDim.y) {      // kSmallMsmMax / kBlock terms per lane at most (16 with mult)
+        const uint32_t t = ipp_term(sp, set, e);
         uint64_t q[4];
         add256(q, (set ? sc2 : sc1)[t], tab.bias);
         int d = (int)window_bits(q, off, cw) - ((1 << (cw - 1)) - 1);
@@ -949,7 +968,7 @@ __global__ void __launch_bounds__(kBlock) k_small_msm(const AffPacked<C>* __rest
         }
     }
     }
-    mine = block_tree_sum_quad<C>(mine, lds, n < (uint32_t)kBlock ? (int)n : kBlock);
+    mine = block_tree_sum_quad<C>(mine, lds, ne < (uint32_t)kBlock ? (int)ne : kBlock);
     if (threadIdx.x == 0) window_sum[tab.roff[w] + blockIdx.y] = xyzz_lazy_pack(mine);
 }
 
