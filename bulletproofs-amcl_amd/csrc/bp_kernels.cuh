@@ -498,7 +498,7 @@ static __global__ void __launch_bounds__(kBlock) k_task_emit(const uint32_t* __r
 // ---------------------------------------------------------------------------------------------- bucket accumulate
 // One lane per task.  The accumulator (4 x 13 limbs) lives in VGPRs for the whole run; points are gathered as
 // 96-byte rows with 16-byte vector loads.  tsum[task] receives the task's sum.  WPS = waves per SIMD the register
-// allocator is asked to fit (2: 174 VGPRs, 3: 168 VGPRs + 16 B scratch, 4: 128 VGPRs + spills, for BLS12-381).
+// allocator is asked to fit (2: 191 VGPRs, no scratch -- profiles/r04_kernel_resources.txt; 3: 168 VGPRs + 156 B scratch and no faster; for BLS12-381).
 template <class C, int WPS>
 __global__ void __launch_bounds__(kBlock, WPS) k_accumulate(const AffPacked<C>* __restrict__ pts, const uint32_t* __restrict__ idx,
                                                        const uint32_t* __restrict__ order, const uint32_t* __restrict__ t_start,
