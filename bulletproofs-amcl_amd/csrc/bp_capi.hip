@@ -808,6 +808,29 @@ int bp_internal_fold_sets(bp_ctx* ctx, int nfolds, const void* const* rec, size_
     return BP_OK;
 }
 
+static bool bp_fr_is_canonical_or_zero(int curve, const uint8_t* x_le32) {
+    uint32_t w[8];
+    memcpy(w, x_le32, 32);
+    return curve == BP_CURVE_BLS12_381 ? words_lt_mod<Bls381Fr>(w) : words_lt_mod<Bn254Fr>(w);
+}
+// out[j] = k1[j] g + k2[j] h for j < count on the HOST (a handful of two-term commitments; bp_host_tail.hpp: Tail::mul2), the count
+// jobs side by side on the context's helper threads.  Inputs must be valid (the callers pass generators and canonical scalars).
+int bp_internal_host_mul2(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const uint8_t* k1_le32, const uint8_t* k2_le32, int count, uint8_t* const* out_le) {
+    if (count <= 0) return BP_OK;
+    const bool ok = ctx->curve == BP_CURVE_BLS12_381 ? Impl<Bls381>::tail().valid_affine(g_le) && Impl<Bls381>::tail().valid_affine(h_le)
+                                                     : Impl<Bn254>::tail().valid_affine(g_le) && Impl<Bn254>::tail().valid_affine(h_le);
+    if (!ok) return BP_ERR_ARG;                              // as bp_g1vec_upload would say of the same bytes
+    for (int j = 0; j < count; j++)
+        if (!bp_fr_is_canonical_or_zero(ctx->curve, k1_le32 + 32 * j) || !bp_fr_is_canonical_or_zero(ctx->curve, k2_le32 + 32 * j)) return BP_ERR_ARG;
+    std::function<void(int)> job = [&](int j) {
+        if (ctx->curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().mul2(g_le, h_le, k1_le32 + 32 * j, k2_le32 + 32 * j, out_le[j]);
+        else Impl<Bn254>::tail().mul2(g_le, h_le, k1_le32 + 32 * j, k2_le32 + 32 * j, out_le[j]);
+    };
+    if (count == 1) job(0);
+    else ctx->tail_pool.run(count, job, count - 1);
+    return BP_OK;
+}
+
 // Window-multiples table of n resident points (bp_g1vec_precompute): allocated from the context's pool, built on its stream.
 int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp_g1table** out) {
     *out = nullptr;

@@ -4,6 +4,8 @@
 // The host keeps the transcript and a handful of scalars, exactly the reference's split; everything with a vector or a group
 // element in it is a bp_* call.  tests/r1cs_twin.py is the same orchestration in the Python mirror; the tests
 // require both to produce the same proof bytes.
+#include <chrono>
+#include <string>
 #include <vector>
 
 #include "bp_internal.hpp"
@@ -109,8 +111,18 @@ struct R1cs {
         RC(commit_scalars(ctx, T, off, n, aL, aR, i_bl, &sc3[0]));
         RC(commit_scalars(ctx, T, off, n, aO, nullptr, o_bl, &sc3[1]));
         RC(commit_scalars(ctx, T, off, n, sL, sR, s_bl, &sc3[2]));
-        uint8_t* out3[3] = {P3, P3 + pb, P3 + 2 * pb};
-        return commit_vectors_concurrent(ctx, GHh, sc3, out3, 3);
+        // A_I and S in ONE pipeline pass over [G | H | h] (two scalar sets, bp_msm_g1_pair), A_O -- all-zero a_O in a gadget circuit, one live
+        // term -- on a sibling context beside it.  (Three separate MSMs in flight took 1.9 ms at 2^16 gates; the uniform S alone is 0.9.)
+        bp_ctx* side = bp_internal_helper(ctx, 0);
+        if (!side) {
+            uint8_t* out3[3] = {P3, P3 + pb, P3 + 2 * pb};
+            return commit_vectors_concurrent(ctx, GHh, sc3, out3, 3);
+        }
+        RC(bp_internal_fork(ctx, side));
+        RC(bp_msm_g1_begin(side, GHh, sc3[1]));
+        const int rc_pair = bp_msm_g1_pair(ctx, GHh, sc3[0], sc3[2], P3, P3 + 2 * pb);
+        const int rc_o = bp_msm_g1_end(side, P3 + pb);
+        return rc_pair ? rc_pair : rc_o;
     }
     // k independent MSMs over the same point vector, three in flight at a time: on the context and its two siblings (the
     // latency-bound bucket reduce and host tail of one hide behind the accumulate of the others).  Every MSM that was begun is
@@ -159,6 +171,22 @@ struct R1cs {
         return BP_OK;
     }
 
+    // BP_PROFILE: wall clock of the prover's phases on stderr (diagnostic)
+    struct Phase {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        std::string log;
+        void lap(bp_ctx* ctx, const char* what) {
+            if (!bp_profile_on()) return;
+            (void)hipStreamSynchronize(ctx->stream);
+            auto t1 = std::chrono::steady_clock::now();
+            char b[96];
+            snprintf(b, sizeof b, "  %s %.0f", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+            log += b;
+            t0 = t1;
+        }
+        ~Phase() { if (bp_profile_on() && !log.empty()) fprintf(stderr, "[bpmsm profile] r1cs prove us:%s\n", log.c_str()); }
+    };
+
     // single phase: bl = i1 o1 s1 t1 t3 t4 t5 t6
     static int prove(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                      const uint8_t* h_le, const bp_frvec* aL, const bp_frvec* aR, const bp_frvec* aO, const bp_frvec* v_blinding, const bp_frvec* sL,
@@ -166,7 +194,9 @@ struct R1cs {
         Temps T;
         const size_t n = aL->n, m = v_blinding ? v_blinding->n : 0;
         memset(proof, 0, proof_bytes(n));
+        Phase ph;
         RC(prove_phase1(ctx, T, t, G, H, h_le, m, n, aL, aR, aO, sL, sR, bl, proof));
+        ph.lap(ctx, "commitments A_I A_O S");
         RC(bp_transcript_append_message(t, (const uint8_t*)"dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11));  // :304-306
         uint8_t zero3[96] = {0};
         return prove_tail(ctx, T, t, plan, G, H, g_le, h_le, n, aL, aR, aO, v_blinding, sL, sR, bl, zero3, bl + 96, proof);
@@ -186,6 +216,7 @@ struct R1cs {
         uint8_t* ab = Rp + lg * pb;
         const Fe<F> i_bl1 = fr_in<F>(bl1), o_bl1 = fr_in<F>(bl1 + 32), s_bl1 = fr_in<F>(bl1 + 64);
         Fe<F> i_bl2 = fe_zero<F>(), o_bl2 = fe_zero<F>(), s_bl2 = fe_zero<F>();                                 // :398-402
+        Phase ph;
         Fe<F> tb[7];
         tb[1] = fr_in<F>(tbl); tb[3] = fr_in<F>(tbl + 32); tb[4] = fr_in<F>(tbl + 64); tb[5] = fr_in<F>(tbl + 96); tb[6] = fr_in<F>(tbl + 128);
         if (n2) {                                                                                              // :385-427: A_I2, A_O2, S2 over G[n1..n), H[n1..n)
@@ -201,6 +232,7 @@ struct R1cs {
         bp_frvec* w[4] = {};
         RC(bp_r1cs_flattened_constraints(ctx, plan, zle, w, nullptr));                                         // :438
         for (auto* v : w) T.keep(v);
+        ph.lap(ctx, "flattened_constraints");
         const bp_frvec* in8[8] = {aL, aR, aO, sL, sR, w[0], w[1], w[2]};
         bp_frvec* lr[6] = {};
         RC(bp_r1cs_prover_polys(ctx, in8, yle, lr));                                                           // :465-486
@@ -214,27 +246,26 @@ struct R1cs {
         RC(bp_vecpoly3_special_inner_product(ctx, lpoly, rpoly, tcoef));                                       // t1..t6, :488
         Fe<F> tc[7];
         for (int k = 1; k <= 6; k++) tc[k] = fr_in<F>(tcoef + 32 * (k - 1));
+        ph.lap(ctx, "polys + special_inner_product");
         std::vector<uint8_t> gh(2 * pb);
         memcpy(gh.data(), g_le, pb);
         memcpy(gh.data() + pb, h_le, pb);
         const int tk[5] = {1, 3, 4, 5, 6};
         static const char* const tlabel[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
-        {   // T_k = t_k g + t_k_blinding h, k = 1, 3, 4, 5, 6 (:496-500): five independent two-term commitments, three in flight at a time
-            bp_g1vec* ghv = nullptr;
-            RC(bp_g1vec_upload(ctx, gh.data(), 2, BP_FMT_LE, &ghv));
-            T.keep(ghv);
-            bp_frvec* tsc[5] = {};
+        {   // T_k = t_k g + t_k_blinding h, k = 1, 3, 4, 5, 6 (:496-500): five two-term commitments of host-side points and scalars -- on the
+            // host, side by side on the helper threads (0.2 ms; as five GPU launches, three in flight at a time, they took 0.77 ms: each is
+            // its upload, its launch and the same 255-doubling tail)
+            uint8_t k1[5 * 32], k2[5 * 32];
             uint8_t* tout[5] = {};
             for (int j = 0; j < 5; j++) {
-                std::vector<uint8_t> sc(64);
-                fr_out<F>(tc[tk[j]], sc.data());
-                fr_out<F>(tb[tk[j]], sc.data() + 32);
-                RC(upload_scalars(ctx, T, sc, &tsc[j]));
+                fr_out<F>(tc[tk[j]], k1 + 32 * j);
+                fr_out<F>(tb[tk[j]], k2 + 32 * j);
                 tout[j] = P + (6 + j) * pb;
             }
-            RC(commit_vectors_concurrent(ctx, ghv, tsc, tout, 5));
+            RC(bp_internal_host_mul2(ctx, g_le, h_le, k1, k2, 5, tout));
         }
         for (int j = 0; j < 5; j++) RC(bp_transcript_commit_point(t, cv, tlabel[j], P + (6 + j) * pb));
+        ph.lap(ctx, "T commitments");
         const Fe<F> u = challenge(t, cv, "u"), x = challenge(t, cv, "x");
         uint8_t ule[32], xle[32];
         fr_out<F>(u, ule); fr_out<F>(x, xle);
@@ -267,9 +298,10 @@ struct R1cs {
         const Fe<F> wch = challenge(t, cv, "w");
         uint8_t Q[pb];
         {
-            std::vector<uint8_t> sc(64, 0);
-            fr_out<F>(wch, sc.data());
-            RC(small_msm(ctx, T, gh, sc, pb, Q));                                                              // Q = w g, :552
+            uint8_t k1[32], k2[32] = {0};
+            uint8_t* qo[1] = {Q};
+            fr_out<F>(wch, k1);
+            RC(bp_internal_host_mul2(ctx, g_le, h_le, k1, k2, 1, qo));                                         // Q = w g, :552
         }
         bp_g1vec *Gp = nullptr, *Hp = nullptr;                                                                 // G[0..pn), H[0..pn): views
         RC(bp_g1vec_wrap_device(ctx, G->d, pn, &Gp));
@@ -281,7 +313,9 @@ struct R1cs {
         Gp->cview = G->ctable ? G->ctable : G->cview;
         Hp->cview = H->ctable ? H->ctable : H->cview;
         size_t lg_out = 0;
+        ph.lap(ctx, "evals, ipp inputs, Q");
         RC(bp_ipp_create(ctx, t, Q, ippin[2], ippin[3], Gp, Hp, ippin[0], ippin[1], Lp, Rp, &lg_out, ab, ab + 32));   // :567-576
+        ph.lap(ctx, "ipp");
         return lg_out == lg ? BP_OK : BP_ERR_DEVICE;
     }
 

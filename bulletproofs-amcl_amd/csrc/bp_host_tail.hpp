@@ -281,6 +281,49 @@ public:
         }
     }
 
+    // k1 g + k2 h for two host-side points and canonical scalars (G1::binary_scalar_mul, /root/reference src/r1cs/prover.rs:496-500:
+    // the five T_k commitments and Q = w g of an R1CS proof).  A shared doubling chain over the 256 bits (Shamir), ~0.2 ms: a GPU launch
+    // for two terms is its host tail (the same 255 doublings) plus the launch, the upload and the synchronisation.
+    // canonical coordinates (< p) and y^2 = x^3 + b, or the all-zero identity: what the device checks on upload (k_points_to_resident)
+    bool valid_affine(const uint8_t* p_le) const {
+        const int fb = 4 * Fp::NW;
+        uint32_t xw[Fp::NW], yw[Fp::NW];
+        memcpy(xw, p_le, fb); memcpy(yw, p_le + fb, fb);
+        uint32_t any = 0;
+        for (int i = 0; i < Fp::NW; i++) any |= xw[i] | yw[i];
+        if (!any) return true;
+        if (!words_lt_mod<Fp>(xw) || !words_lt_mod<Fp>(yw)) return false;
+        uint64_t x[N] = {}, y[N] = {}, xm[N], ym[N], t[N], rhs[N], b[N] = {}, bm[N];
+        for (int i = 0; i < Fp::NW; i++) { x[i / 2] |= (uint64_t)xw[i] << (32 * (i & 1)); y[i / 2] |= (uint64_t)yw[i] << (32 * (i & 1)); }
+        b[0] = C::B;
+        f.mul(xm, x, f.r2); f.mul(ym, y, f.r2); f.mul(bm, b, f.r2);
+        f.sqr(t, xm); f.mul(rhs, t, xm); f.add(rhs, rhs, bm);
+        f.sqr(t, ym);
+        for (int i = 0; i < N; i++) if (t[i] != rhs[i]) return false;
+        return true;
+    }
+    void mul2(const uint8_t* g_le, const uint8_t* h_le, const uint8_t* k1_le32, const uint8_t* k2_le32, uint8_t* out_le) const {
+        const int fb = 4 * Fp::NW;
+        uint32_t xw[Fp::NW], yw[Fp::NW];
+        memcpy(xw, g_le, fb); memcpy(yw, g_le + fb, fb);
+        const Jac g = jac_from_affine(xw, yw);
+        memcpy(xw, h_le, fb); memcpy(yw, h_le + fb, fb);
+        const Jac h = jac_from_affine(xw, yw);
+        Jac gh = g;
+        add(gh, h);
+        Jac acc;
+        memset(&acc, 0, sizeof acc);
+        acc.inf = true;
+        for (int bit = 255; bit >= 0; bit--) {
+            dbl(acc);
+            const int b1 = (k1_le32[bit >> 3] >> (bit & 7)) & 1, b2 = (k2_le32[bit >> 3] >> (bit & 7)) & 1;
+            if (b1 & b2) add(acc, gh);
+            else if (b1) add(acc, g);
+            else if (b2) add(acc, h);
+        }
+        finish(&acc, 1, out_le);
+    }
+
     // chain `k` of `chains`: Horner over every chains-th non-identity record (in descending bit position), all the way down to bit 0
     void fold_chain(const XyzzPacked<C>* rec, size_t sets, int nrec, const uint16_t* pos, int k, int chains, Jac* out) const {
         Jac acc;

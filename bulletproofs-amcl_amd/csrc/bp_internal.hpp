@@ -288,6 +288,8 @@ extern "C" int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling);
 int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
                      size_t nnz, const bp_g1table* tb = nullptr);
 int bp_internal_set_device(const bp_ctx* ctx);
+// a few two-term commitments k1 g + k2 h on the host (bp_capi.hip)
+int bp_internal_host_mul2(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const uint8_t* k1_le32, const uint8_t* k2_le32, int count, uint8_t* const* out_le);
 // building blocks of the sharded inner-product argument (bp_capi.hip)
 int bp_internal_pair_width(bp_ctx* ctx, size_t n, size_t nnz);
 int bp_internal_msm2_begin(bp_ctx* ctx, const void* pts, const void* sc1, const void* sc2, size_t n, int c, size_t nnz, const bp_g1table* tb, int* nrec_out,
