@@ -175,7 +175,7 @@ __device__ __forceinline__ HashMsg make_msg(const uint8_t* bytes, const uint64_t
 // leaves the loop once the counter passes n (each try succeeds with probability 1/2, so the loop terminates).
 // out[i] = (x, even y) on the curve, cofactor not yet cleared; message i as in k_hash_to_g1 below.
 template <class C>
-__global__ void __launch_bounds__(kHashBlock, 2) k_hash_search(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs, uint32_t prefix_len,
+__global__ void __launch_bounds__(kHashBlock, 1) k_hash_search(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs, uint32_t prefix_len,
                                                                uint64_t first, size_t n, SqrtExp e, unsigned long long* __restrict__ next,
                                                                AffPacked<C>* __restrict__ out) {
     using Fp = typename C::Fp;

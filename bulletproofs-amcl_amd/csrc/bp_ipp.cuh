@@ -384,7 +384,10 @@ __global__ void __launch_bounds__(kBlock) k_ipp_pack_round(const AffPacked<C>* _
 // k1*p + k2*q with one shared doubling chain (Shamir), k1/k2 canonical words.  (G1::binary_scalar_mul)
 // The two scalars are held in 64-bit registers and shifted left one bit per step (static indexing only: no
 // per-lane scratch arrays, no divergent trip counts -- leading zero bits just double the identity).
-template <class C>
+// ONE_SITE: the three kinds of addition (+ p, + q, + (p + q)) go through ONE full-addition call site on a selected operand instead of
+// two mixed and one full: ~15 % more field work per step, a third of the code -- k_ipp_fold<Bls381>, which also folds a and b in the
+// same kernel, needed 512 VGPRs + 256 AGPRs and still spilled 60 registers with the three sites (profiles/r04_kernel_resources.txt).
+template <class C, bool ONE_SITE = false>
 BP_HD Xyzz<C> xyzz_mul2_words(const ScalarWords& k1, const Aff<C>& p, const ScalarWords& k2, const Aff<C>& q) {
     Xyzz<C> pq = xyzz_add_aff(xyzz_from_aff(p), q);   // p + q, with p == +-q and identities handled
     Xyzz<C> acc = xyzz_inf<C>();
@@ -397,9 +400,16 @@ BP_HD Xyzz<C> xyzz_mul2_words(const ScalarWords& k1, const Aff<C>& p, const Scal
         a3 = (a3 << 1) | (a2 >> 63); a2 = (a2 << 1) | (a1 >> 63); a1 = (a1 << 1) | (a0 >> 63); a0 <<= 1;
         b3 = (b3 << 1) | (b2 >> 63); b2 = (b2 << 1) | (b1 >> 63); b1 = (b1 << 1) | (b0 >> 63); b0 <<= 1;
         acc = xyzz_dbl(acc);
-        if (ba & bb) acc = xyzz_add(acc, pq);
-        else if (ba) acc = xyzz_add_aff(acc, p);
-        else if (bb) acc = xyzz_add_aff(acc, q);
+        if (ONE_SITE) {
+            if (ba | bb) {
+                const Xyzz<C> sel = (ba & bb) ? pq : ba ? xyzz_from_aff(p) : xyzz_from_aff(q);
+                acc = xyzz_add(acc, sel);
+            }
+        } else {
+            if (ba & bb) acc = xyzz_add(acc, pq);
+            else if (ba) acc = xyzz_add_aff(acc, p);
+            else if (bb) acc = xyzz_add_aff(acc, q);
+        }
     }
     return acc;
 }
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(kBlock) k_ipp_fold(AffPacked<C>* __restrict__ 
         fe_pack_words<F>(k2.w, fe_from_mont<F>(sR));
     }
     Aff<C> p = aff_unpack(V[i]), q = aff_unpack(V[h + i]);
-    Xyzz<C> r = xyzz_mul2_words<C>(k1, p, k2, q);
+    Xyzz<C> r = xyzz_mul2_words<C, true>(k1, p, k2, q);
     V[i] = aff_pack(xyzz_to_aff<C>(r));
 }
 
