@@ -993,6 +993,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
                       &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags}) b->release();
     if (ctx->pool) { ctx->pool->trim(); ctx->pool->release(); }     // cached blocks go back to the driver now; live handles keep the (empty) pool alive
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->ev_ready) for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1331,6 +1332,27 @@ int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec
     if (rc) { bp_frvec_free(*out); *out = nullptr; }
     return rc;
     });
+}
+
+int bp_internal_frvec_upload_trusted(bp_ctx* ctx, const uint8_t* le32, size_t n, bp_frvec** out) {
+    constexpr size_t kStage = (size_t)1 << 20;
+    const size_t bytes = n * 32;
+    if (bytes == 0 || bytes > kStage / 4) return bp_frvec_upload(ctx, le32, n, out);
+    if (!ctx->stage) {
+        if (hipHostMalloc(&ctx->stage, kStage, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->stage = nullptr; return bp_frvec_upload(ctx, le32, n, out); }
+        ctx->stage_cap = kStage; ctx->stage_cur = 0;
+    }
+    if (ctx->stage_cur + bytes > ctx->stage_cap) {          // wrap: everything staged so far must have left the ring
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->stage_cur = 0;
+    }
+    int rc = bp_frvec_alloc(ctx, n, out);
+    if (rc) return rc;
+    uint8_t* slot = (uint8_t*)ctx->stage + ctx->stage_cur;
+    ctx->stage_cur += (bytes + 63) & ~(size_t)63;
+    memcpy(slot, le32, bytes);
+    if (hipMemcpyAsync((*out)->d, slot, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { bp_frvec_free(*out); *out = nullptr; return BP_ERR_DEVICE; }
+    return BP_OK;
 }
 
 int bp_frvec_download(bp_ctx* ctx, const bp_frvec* v, size_t offset, size_t n, uint8_t* out_le32) {

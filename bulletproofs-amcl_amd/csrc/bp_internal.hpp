@@ -147,6 +147,8 @@ struct bp_ctx {
     DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
+    void* stage = nullptr;              // page-locked ring for small host -> device copies of LIBRARY-made data that must not wait for the
+    size_t stage_cap = 0, stage_cur = 0;   // stream (bp_internal_frvec_upload_trusted): a slice is reused only after a synchronisation
     hipEvent_t ev[8] = {};              // stage boundaries of the last MSM (created on first use, only when timing is on)
     bool ev_ready = false;
     float last_ms[8] = {};
@@ -288,6 +290,9 @@ extern "C" int bp_internal_fork(bp_ctx* ctx, bp_ctx* sibling);
 int bp_internal_msm2(bp_ctx* ctx, const void* points, const void* scalars1, const void* scalars2, size_t n, uint8_t* out1_le, uint8_t* out2_le,
                      size_t nnz, const bp_g1table* tb = nullptr);
 int bp_internal_set_device(const bp_ctx* ctx);
+// n canonical scalars the LIBRARY produced (challenges, their powers, blinding combinations) -> a resident vector, without the
+// canonicity check and without waiting for the stream (the bytes are staged in the context's page-locked ring)
+extern "C" int bp_internal_frvec_upload_trusted(bp_ctx* ctx, const uint8_t* le32, size_t n, bp_frvec** out);
 // a few two-term commitments k1 g + k2 h on the host (bp_capi.hip)
 int bp_internal_host_mul2(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const uint8_t* k1_le32, const uint8_t* k2_le32, int count, uint8_t* const* out_le);
 // building blocks of the sharded inner-product argument (bp_capi.hip)
