@@ -275,7 +275,7 @@ struct Ipp {
         return BP_OK;
     }
 
-    // L, R of a round after a GLV compaction: the round's scalars are split in place, k_small_msm_glv leaves 26 x splits records per
+    // L, R of a round after a GLV compaction (the round's scalars arrive split: k_ipp_round_prep<C, true>): k_small_msm_glv leaves 26 x splits records per
     // scalar set at bit positions 5 w, the host folds two tails of <= 125 doublings
     static int msm2_glv(bp_ipp_state* st, uint8_t* L_le, uint8_t* R_le) {
         bp_ctx* ctx = st->ctx;
@@ -287,8 +287,6 @@ struct Ipp {
         bp_prof().lap(0);
         if ((rc = ctx->window_sum.reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
-        hipLaunchKernelGGL(k_glv_decompose<C>, dim3(blocks_for(m)), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, m, (ScalarWords*)st->sL,
-                           (ScalarWords*)st->sR);
         const IppSparse sp = st->n >= 2 ? IppSparse{(uint32_t)st->n0, (uint32_t)st->n, (uint32_t)(st->n / 2)} : IppSparse{0, 0, 0};
         hipLaunchKernelGGL(k_small_msm_glv<C>, dim3(kGlvWin, 2, splits), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)m,
                            (const AffPacked<C>*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p, sp);
@@ -372,25 +370,42 @@ struct Ipp {
         auto* a = (ScalarWords*)st->a; auto* b = (ScalarWords*)st->b;
         auto* cLR = (ScalarWords*)st->cLR;
         int rc;
-        {   // c_L = <a_L, b_R>, c_R = <a_R, b_L> (src/ipp.rs:77-78, 145-146): both in one launch pair
-            unsigned g = blocks_for(h);
-            if (g > kInnerBlocks / 2) g = kInnerBlocks / 2;
-            if (g == 0) g = 1;
-            hipLaunchKernelGGL(k_fr_inner2<C>, dim3(g, 2), dim3(kBlock), 0, ctx->stream, a, b + h, a + h, b, h, (ScalarWords*)st->partial);
-            hipLaunchKernelGGL(k_fr_inner2_final<C>, dim3(2), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)st->partial, g, cLR);
-            HIPCHK(hipGetLastError());
-        }
+        unsigned g = blocks_for(h);
+        if (g > kInnerBlocks / 2) g = kInnerBlocks / 2;
+        if (g == 0) g = 1;
         if (!st->fold_generators) {
+            // c_L = <a_L, b_R>, c_R = <a_R, b_L> (src/ipp.rs:77-78, 145-146) and the round's L / R scalars: two launches (k_ipp_round_prep / _final)
             size_t m = 2 * st->n0 + 1;
-            hipLaunchKernelGGL(k_ipp_round_scalars<C>, dim3(blocks_for(st->n0)), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG,
-                               (const ScalarWords*)st->cH, cLR, st->n0, (size_t)0, st->n, (ScalarWords*)st->sL, (ScalarWords*)st->sR, 1);
+            unsigned gx = blocks_for(st->n0);                 // the scalar row: a lane per generator (up to 1024 blocks, then grid-stride)
+            if (gx > 1024) gx = 1024;
+            if (gx < g) gx = g;
+            bool split = false;
+            if constexpr (C::HAS_GLV) split = st->compacted && st->table && st->table->glv;
+            if (split) {
+                if constexpr (C::HAS_GLV) {
+                    hipLaunchKernelGGL((k_ipp_round_prep<C, true>), dim3(gx, 3), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, st->n0,
+                                       st->n, g, (ScalarWords*)st->partial, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
+                    hipLaunchKernelGGL((k_ipp_round_final<C, true>), dim3(2), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)st->partial, g, cLR, st->n0, (ScalarWords*)st->sL,
+                                       (ScalarWords*)st->sR);
+                }
+            } else {
+                hipLaunchKernelGGL((k_ipp_round_prep<C, false>), dim3(gx, 3), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, st->n0,
+                                   st->n, g, (ScalarWords*)st->partial, (ScalarWords*)st->sL, (ScalarWords*)st->sR);
+                hipLaunchKernelGGL((k_ipp_round_final<C, false>), dim3(2), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)st->partial, g, cLR, st->n0, (ScalarWords*)st->sL,
+                                   (ScalarWords*)st->sR);
+            }
             HIPCHK(hipGetLastError());
             BP_TRACE_SYNC(ctx, "ipp round scalars");
-            if constexpr (C::HAS_GLV) { if (st->compacted && st->table && st->table->glv) return msm2_glv(st, L_le, R_le); }
+            if constexpr (C::HAS_GLV) { if (split) return msm2_glv(st, L_le, R_le); }
             ctx->ipp_n0 = (uint32_t)st->n0; ctx->ipp_live = (uint32_t)st->n;       // single-launch rounds walk the participating terms only
             const int rcm = bp_internal_msm2(ctx, st->Pall, st->sL, st->sR, m, L_le, R_le, st->n0 + 1, st->table);   // both sums in one pipeline pass
             ctx->ipp_n0 = 0; ctx->ipp_live = 0;
             return rcm;
+        }
+        {   // reference-shaped mode
+            hipLaunchKernelGGL(k_fr_inner2<C>, dim3(g, 2), dim3(kBlock), 0, ctx->stream, a, b + h, a + h, b, h, (ScalarWords*)st->partial);
+            hipLaunchKernelGGL(k_fr_inner2_final<C>, dim3(2), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)st->partial, g, cLR);
+            HIPCHK(hipGetLastError());
         }
         hipLaunchKernelGGL(k_ipp_pack_round<C>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->G,
                            (const AffPacked<C>*)st->H, a, b, st->first ? (const ScalarWords*)st->gf : nullptr,

@@ -382,6 +382,16 @@ __device__ __forceinline__ void glv_decompose(const ScalarWords& sw, uint64_t (&
     s1[0] = r0; s1[1] = r1; s2[0] = q0; s2[1] = q1;
 }
 
+// dst[i] = the two halves of a canonical scalar (the store of k_ipp_round_prep / _final<C, true>, bp_ipp.cuh)
+template <class C> __device__ __forceinline__ void glv_split_store(ScalarWords* dst, size_t i, const ScalarWords& canonical) {
+    uint64_t a[2], b[2];
+    glv_decompose<C>(canonical, a, b);
+    ScalarWords o;
+    o.w[0] = (uint32_t)a[0]; o.w[1] = (uint32_t)(a[0] >> 32); o.w[2] = (uint32_t)a[1]; o.w[3] = (uint32_t)(a[1] >> 32);
+    o.w[4] = (uint32_t)b[0]; o.w[5] = (uint32_t)(b[0] >> 32); o.w[6] = (uint32_t)b[1]; o.w[7] = (uint32_t)(b[1] >> 32);
+    dst[i] = o;
+}
+
 // out1[i] = split(in1[i]), out2[i] = split(in2[i]) (in place allowed); in2 == nullptr: one vector
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_glv_decompose(const ScalarWords* in1, const ScalarWords* in2, size_t n, ScalarWords* out1, ScalarWords* out2) {

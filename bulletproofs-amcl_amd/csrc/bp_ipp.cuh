@@ -501,6 +501,67 @@ __global__ void __launch_bounds__(kBlock) k_ipp_round_scalars(const ScalarWords*
     if (k == 0) { sL[2 * nloc] = with_q ? cLR[0] : zero; sR[2 * nloc] = with_q ? cLR[1] : zero; }
 }
 
+// The same two jobs of a round in ONE launch (round 4: a single-launch round is ~140 us of MSM kernel behind ~30 us of these small
+// kernels, each with its own launch gap): grid (max(g, blocks of nloc), 3) -- rows 0 / 1 the partial sums of c_L = <a_lo, b_hi> / c_R = <a_hi, b_lo> (as
+// k_fr_inner2), row 2 the L / R scalars of the nloc generators (as k_ipp_round_scalars, grid-stride) -- without the Q terms, which need
+// c_L, c_R and are written by k_ipp_round_final.  SPLIT (BLS12-381 after a compaction): every scalar is stored as its two GLV halves.
+// glv_split_store is defined by bp_compact.cuh (included after this header by the one translation unit that instantiates SPLIT = true).
+template <class C> __device__ __forceinline__ void glv_split_store(ScalarWords* dst, size_t i, const ScalarWords& canonical);
+template <class C, bool SPLIT>
+__global__ void __launch_bounds__(kBlock) k_ipp_round_prep(const ScalarWords* __restrict__ a, const ScalarWords* __restrict__ b,
+                                                           const ScalarWords* __restrict__ cG, const ScalarWords* __restrict__ cH, size_t nloc, size_t nj,
+                                                           uint32_t g, ScalarWords* __restrict__ partial, ScalarWords* __restrict__ sL, ScalarWords* __restrict__ sR) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    const size_t h = nj / 2, stride = (size_t)gridDim.x * blockDim.x;
+    if (blockIdx.y < 2) {                                // the first g blocks of rows 0 / 1 (the grid is as wide as the scalar row needs)
+        if (blockIdx.x >= g) return;
+        const ScalarWords* x = blockIdx.y ? a + h : a;
+        const ScalarWords* y = blockIdx.y ? b : b + h;
+        Fe<F> acc = fe_zero<F>();
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < h; i += (size_t)g * blockDim.x) acc = fe_add(acc, fe_mul(fr_load<F>(x, i), fr_load<F>(y, i)));
+        acc = block_fr_sum<F>(acc, lds);
+        if (threadIdx.x == 0) fr_store<F>(partial, (size_t)blockIdx.y * g + blockIdx.x, acc);
+        return;
+    }
+    ScalarWords zero;
+    for (int i = 0; i < 8; i++) zero.w[i] = 0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < nloc; k += stride) {
+        const size_t pos = k & (nj - 1);
+        const bool upper = pos >= h;
+        // canonical * canonical / R, then * R^2 / R  ->  canonical product
+        ScalarWords g, hh;
+        fe_pack_words<F>(g.w, fe_to_mont<F>(fe_mul(fr_load<F>(a, upper ? pos - h : h + pos), fr_load<F>(cG, k))));
+        fe_pack_words<F>(hh.w, fe_to_mont<F>(fe_mul(fr_load<F>(b, upper ? pos - h : h + pos), fr_load<F>(cH, k))));
+        // L: G upper, H lower;  R: G lower, H upper  (zero = zero in split form too)
+        if (SPLIT) {
+            if (upper) { glv_split_store<C>(sL, k, g); sR[k] = zero; sL[nloc + k] = zero; glv_split_store<C>(sR, nloc + k, hh); }
+            else { sL[k] = zero; glv_split_store<C>(sR, k, g); glv_split_store<C>(sL, nloc + k, hh); sR[nloc + k] = zero; }
+        } else {
+            if (upper) { sL[k] = g; sR[k] = zero; sL[nloc + k] = zero; sR[nloc + k] = hh; }
+            else { sL[k] = zero; sR[k] = g; sL[nloc + k] = hh; sR[nloc + k] = zero; }
+        }
+    }
+}
+// blocks 0 / 1: c_L / c_R = R * (sum of the m partials) -> cLR[blockIdx.x], and the scalar of Q in the round's L / R set
+template <class C, bool SPLIT>
+__global__ void __launch_bounds__(kBlock) k_ipp_round_final(const ScalarWords* __restrict__ partial, uint32_t m, ScalarWords* __restrict__ cLR, size_t nloc,
+                                                            ScalarWords* __restrict__ sL, ScalarWords* __restrict__ sR) {
+    using F = typename C::Fr;
+    __shared__ ScalarWords lds[kBlock];
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) acc = fe_add(acc, fr_load<F>(partial, (size_t)blockIdx.x * m + i));
+    acc = block_fr_sum<F>(acc, lds);
+    if (threadIdx.x == 0) {
+        ScalarWords c;
+        fe_pack_words<F>(c.w, fe_to_mont<F>(acc));
+        cLR[blockIdx.x] = c;
+        ScalarWords* dst = blockIdx.x ? sR : sL;
+        if (SPLIT) glv_split_store<C>(dst, 2 * nloc, c);
+        else dst[2 * nloc] = c;
+    }
+}
+
 // cG_k *= (pos < h ? u^-1 : u); cH_k *= (pos < h ? u : u^-1); a, b folded (src/ipp.rs:116-129, 182-187).
 // grid covers max(nloc, nj / 2) threads: the coefficient slice and the (replicated) a, b are independent jobs.
 template <class C>
