@@ -74,10 +74,15 @@ def time_ipp(ctx, n, seed, oracle=False, tables=True):
         t_build = time.perf_counter() - t0
         tt, proof_t = best_of(lambda: bp.IPP.create_ipp(ctx, bp.Transcript(b"innerproduct"), Q, Gf, Hf, Gv, Hv, a, b))
         cw, W, nbytes = Gv.table_info()
-        res["with_tables"] = {"create_ms": tt * 1e3, "same_proof_bytes": bool((proof_t.L, proof_t.R, proof_t.a, proof_t.b) == (proof.L, proof.R, proof.a, proof.b)),
+        ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 2)                  # opt-in (measured, not faster: DESIGN.md section 5)
+        bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)   # builds the context's [G | H] table
+        tvt, _ = best_of(lambda: bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"innerproduct"), Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R))
+        res["with_tables"] = {"create_ms": tt * 1e3, "verify_over_tables_ms": tvt * 1e3, "same_proof_bytes": bool((proof_t.L, proof_t.R, proof_t.a, proof_t.b) == (proof.L, proof.R, proof.a, proof.b)),
                               "window_bits": cw, "windows": W, "table_bytes_G_plus_H": 2 * nbytes, "table_build_ms_once_per_generator_set": t_build * 1e3}
         Gv.drop_table()
         Hv.drop_table()
+        ctx.drop_verify_table()
+        ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 0)
     if oracle:
         args = (Gf.to_bytes(), Hf.to_bytes(), Gv.to_bytes(), Hv.to_bytes(), a.to_bytes(), b.to_bytes())
         t0 = time.perf_counter()
@@ -275,10 +280,18 @@ def cfg3_e2e():
     ctx.synchronize()
     t_tables = time.perf_counter() - t0
     tpt, proof_t = best_of(do_prove, reps=3)
-    tables = {"prove_ms": tpt * 1e3, "same_proof_bytes": bool(proof_t == proof), "window_bits": gens.G.table_info()[0], "table_bytes_G_plus_H": 2 * gens.G.table_info()[2],
+    ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 4096)                      # opt-in (measured, not faster: DESIGN.md section 5)
+    do_verify(proof)                                                # first verification over the tables builds the context's [G | H] table
+    tvt, okt = best_of(lambda: do_verify(proof), reps=3)
+    bad_t = bytearray(proof)
+    bad_t[11 * ctx.point_bytes] ^= 1
+    tables = {"prove_ms": tpt * 1e3, "verify_over_tables_ms": tvt * 1e3, "accepted": bool(okt), "tampered_rejected": not do_verify(bytes(bad_t)),
+              "verify_table_bytes_kept_on_the_context": ctx.verify_table_info()[1], "same_proof_bytes": bool(proof_t == proof), "window_bits": gens.G.table_info()[0], "table_bytes_G_plus_H": 2 * gens.G.table_info()[2],
               "table_build_ms_once_per_generator_set": t_tables * 1e3}
     gens.G.drop_table()
     gens.H.drop_table()
+    ctx.drop_verify_table()
+    ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 0)
     tpp, pyproof = best_of(py_prove, reps=2)
     tpv, pyok = best_of(lambda: R1.verify(ctx, gens, plan, R1.start_transcript(ctx, b"cfg3", V), V, pyproof), reps=2)
     ipp = pyproof["ipp"]

@@ -18,7 +18,7 @@ _SO = os.environ.get("BPMSM_SO") or os.path.join(_HERE, "libbpmsm.so")   # overr
 BP_OK, BP_ERR_LENGTH, BP_ERR_ARG, BP_ERR_VERIFY, BP_ERR_DEVICE = 0, 1, 2, 3, 4
 BLS12_381, BN254 = 0, 1
 FMT_LE, FMT_AMCL = 0, 1
-TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM, TUNE_TAIL_CHAINS, TUNE_COMPACT_AT, TUNE_GLV = 1, 2, 3, 4, 5, 6, 7   # bp_ctx_set_tuning knobs (include/bpmsm.h)
+TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM, TUNE_TAIL_CHAINS, TUNE_COMPACT_AT, TUNE_GLV, TUNE_VERIFY_TABLES = 1, 2, 3, 4, 5, 6, 7, 8   # bp_ctx_set_tuning knobs (include/bpmsm.h)
 CURVE_IDS = {"bls12_381": BLS12_381, "bn254": BN254}
 
 
@@ -79,6 +79,8 @@ SYMBOLS = {
     "bp_g1vec_free": (_I, [_P]),
     "bp_g1vec_precompute": (_I, [_P, _P, _I]),
     "bp_g1vec_drop_table": (_I, [_P]),
+    "bp_ctx_verify_table_info": (_I, [_P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "bp_ctx_drop_verify_table": (_I, [_P]),
     "bp_g1vec_table_info": (_I, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t)]),
     "bp_g1vec_len": (_SZ, [_P]),
     "bp_g1vec_device_ptr": (_P, [_P]),
@@ -258,8 +260,17 @@ class Context:
         _check(lib().bp_ctx_set_window_bits(self.h, c), "bp_ctx_set_window_bits")
 
     def set_tuning(self, knob, value):
-        """validated engineering knobs of the MSM pipeline (TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM, TUNE_TAIL_CHAINS, TUNE_COMPACT_AT); 0 = automatic"""
+        """validated engineering knobs of the MSM pipeline (TUNE_TILE, TUNE_REDUCE_M, TUNE_TASK_TARGET, TUNE_SMALL_MSM, TUNE_TAIL_CHAINS, TUNE_COMPACT_AT, TUNE_GLV, TUNE_VERIFY_TABLES); 0 = automatic"""
         _check(lib().bp_ctx_set_tuning(self.h, knob, value), "bp_ctx_set_tuning")
+
+    def verify_table_info(self):
+        """-> (generators per vector, bytes) of the [G | H] table this context keeps for its verifiers (TUNE_VERIFY_TABLES); zeros without one"""
+        n, b = ctypes.c_size_t(), ctypes.c_size_t()
+        _check(lib().bp_ctx_verify_table_info(self.h, ctypes.byref(n), ctypes.byref(b)), "bp_ctx_verify_table_info")
+        return n.value, b.value
+
+    def drop_verify_table(self):
+        _check(lib().bp_ctx_drop_verify_table(self.h), "bp_ctx_drop_verify_table")
 
     def set_ipp_fold_generators(self, on):
         _check(lib().bp_ctx_set_ipp_fold_generators(self.h, 1 if on else 0), "bp_ctx_set_ipp_fold_generators")

@@ -338,7 +338,7 @@ struct Impl {
         if ((rc = ctx->tsum.reserve(ctx, max_tasks * kXyzzBytes))) return rc;
         if ((rc = ctx->heavy.reserve(ctx, max_heavy * 4))) return rc;
         if ((rc = ctx->heavy_chunks.reserve(ctx, max_chunks * sizeof(uint2)))) return rc;
-        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16 + 2 * kMaxWindows;      // + per window: "blocks done" (k_bucket_reduce), non-empty buckets
+        constexpr size_t kMetaWords = ((kTaskBins + 3 + 15) / 16) * 16 + 2 * kMaxWindows + 16;   // + per window: "blocks done" (k_bucket_reduce), non-empty buckets; + the slice count of huge bins
         if ((rc = ctx->meta.reserve(ctx, kMetaWords * 4))) return rc;
         if ((rc = ctx->partial.reserve(ctx, (size_t)tabR.rboff[WR] * kPartPerBlock * kXyzzBytes))) return rc;
         uint32_t* count = (uint32_t*)ctx->count.p;       // bucket starts
@@ -374,6 +374,15 @@ struct Impl {
         uint32_t* nchunks = bins + kTaskBins + 2;
         uint32_t* win_done = bins + ((kTaskBins + 3 + 15) / 16) * 16;
         uint32_t* nonempty = win_done + kMaxWindows;                    // per window: buckets that hold anything (k_fine_place -> task_len)
+        uint32_t* nslices = nonempty + kMaxWindows;
+        // Huge coarse bins (structured scalars: bit vectors, a few distinct values, small values) get a block per 8192 records instead of
+        // one block for the bin -- from 2^22 records on, where one block streaming half of them was the whole sort.
+        const size_t nrecs = (size_t)W * n;
+        static const size_t huge_from = getenv("BP_HUGE_FROM") ? (size_t)atol(getenv("BP_HUGE_FROM")) : (size_t)1 << 22;
+        const size_t max_slices = nrecs >= huge_from ? nrecs / kHugeSlice + nrecs / kHugeMin + 2 : 0;
+        if (max_slices && (rc = ctx->huge.reserve(ctx, max_slices * (sizeof(HugeSlice) + kBlock * 4)))) return rc;
+        HugeSlice* slices = max_slices ? (HugeSlice*)ctx->huge.p : nullptr;
+        uint32_t* slice_hist = max_slices ? (uint32_t*)((uint8_t*)ctx->huge.p + max_slices * sizeof(HugeSlice)) : nullptr;
         uint32_t* order = (uint32_t*)ctx->order.p;
         uint32_t* t_start = (uint32_t*)ctx->t_start.p;
         uint32_t* t_len = (uint32_t*)ctx->t_len.p;
@@ -392,7 +401,12 @@ struct Impl {
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, W), dim3(kBlock), 0, st, code, n, tab, ntiles, tile_hist, tmp_rec, 0, tile);
         BP_TRACE_SYNC(ctx, "k_coarse_scatter");
-        hipLaunchKernelGGL(k_fine_place, dim3(128, WR), dim3(kBlock), 0, st, tmp_rec, tabR, ncols, tile_hist, hsum + hist_blocks, count, cursor, idx, 0, nonempty);
+        hipLaunchKernelGGL(k_fine_place, dim3(128, WR), dim3(kBlock), 0, st, tmp_rec, tabR, ncols, tile_hist, hsum + hist_blocks, count, cursor, idx, 0, nonempty, slices, nslices);
+        if (max_slices) {
+            const unsigned sg = (unsigned)(max_slices < 2048 ? max_slices : 2048);
+            hipLaunchKernelGGL(k_fine_huge_count, dim3(sg), dim3(kBlock), 0, st, tmp_rec, tabR, slices, nslices, slice_hist);
+            hipLaunchKernelGGL(k_fine_huge_place, dim3(sg), dim3(kBlock), 0, st, tmp_rec, tabR, slices, nslices, slice_hist, count, cursor, idx, nonempty);
+        }
         BP_TRACE_SYNC(ctx, "k_fine_place");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[3], st));
         // count[] = bucket starts, cursor[] = bucket ends
@@ -831,6 +845,11 @@ int bp_internal_host_mul2(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le,
     return BP_OK;
 }
 
+static uint64_t next_table_id() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
+
 // Window-multiples table of n resident points (bp_g1vec_precompute): allocated from the context's pool, built on its stream.
 int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp_g1table** out) {
     *out = nullptr;
@@ -841,7 +860,7 @@ int bp_internal_table_build(bp_ctx* ctx, const void* points, size_t n, int c, bp
     const size_t pt = 2 * (size_t)fp_bytes_of(ctx->curve), xz = bp_msm_record_bytes(ctx->curve);
     bp_g1table* t = new (std::nothrow) bp_g1table();
     if (!t) return BP_ERR_DEVICE;
-    t->pool = ctx->pool; t->device = ctx->device; t->n = n; t->c = c; t->W = W1;
+    t->pool = ctx->pool; t->device = ctx->device; t->n = n; t->c = c; t->W = W1; t->id = next_table_id();
     t->d = ctx->pool->get((size_t)W1 * n * pt, &t->cap);
     PoolBlock tmp, pre;                                                        // parked XYZZ values and running products (returned to the pool in stream order)
     if (!t->d || !tmp.alloc(ctx, (size_t)(W1 - 1) * n * xz + 16) || !pre.alloc(ctx, (size_t)(W1 - 1) * n * (pt / 2) + 16)) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
@@ -889,13 +908,13 @@ int bp_internal_table_concat(bp_ctx* ctx, const bp_g1vec* G, size_t offG, const 
     if (!G->table) offG += G->tview_off;
     if (!H->table) offH += H->tview_off;
     if (!tg || !th || tg->c != th->c || tg->W != th->W || offG + n > tg->n || offH + n > th->n) return BP_OK;
-    const size_t m = 2 * n + 1;
+    const size_t m = 2 * n + (extra_le ? 1 : 0);         // extra_le == NULL: [G | H] alone (the verifiers' table, bp_internal_gh_table)
     const int W1 = tg->W, c = tg->c;
     if ((uint64_t)W1 * m >= ((uint64_t)1 << 31)) return BP_OK;
     const size_t pt = 2 * (size_t)fp_bytes_of(ctx->curve);
     bp_g1table* t = new (std::nothrow) bp_g1table();
     if (!t) return BP_ERR_DEVICE;
-    t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = c; t->W = W1;
+    t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = c; t->W = W1; t->id = next_table_id();
     t->d = ctx->pool->get((size_t)W1 * m * pt, &t->cap);
     PoolBlock raw, conv;
     if (!t->d || !raw.alloc(ctx, (size_t)W1 * pt) || !conv.alloc(ctx, (size_t)W1 * pt)) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
@@ -904,10 +923,13 @@ int bp_internal_table_concat(bp_ctx* ctx, const bp_g1vec* G, size_t offG, const 
     hipStream_t s = ctx->stream;
     // the pinned staging buffer may still be the source / target of an earlier copy on this stream
     if (hipStreamSynchronize(s) != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
-    if (ctx->curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().window_multiples(extra_le, c, W1, (uint8_t*)ctx->host_pinned);
-    else Impl<Bn254>::tail().window_multiples(extra_le, c, W1, (uint8_t*)ctx->host_pinned);
-    bool ok = hipMemcpyAsync(raw.p, ctx->host_pinned, (size_t)W1 * pt, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok) {
+    bool ok = true;
+    if (extra_le) {
+        if (ctx->curve == BP_CURVE_BLS12_381) Impl<Bls381>::tail().window_multiples(extra_le, c, W1, (uint8_t*)ctx->host_pinned);
+        else Impl<Bn254>::tail().window_multiples(extra_le, c, W1, (uint8_t*)ctx->host_pinned);
+        ok = hipMemcpyAsync(raw.p, ctx->host_pinned, (size_t)W1 * pt, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
+    if (ok && extra_le) {
         if (ctx->curve == BP_CURVE_BLS12_381)
             hipLaunchKernelGGL(k_points_to_resident<Bls381>, dim3((unsigned)((W1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, (const uint32_t*)raw.p, (size_t)W1, (AffPacked<Bls381>*)conv.p, (uint32_t*)nullptr);
         else
@@ -919,12 +941,92 @@ int bp_internal_table_concat(bp_ctx* ctx, const bp_g1vec* G, size_t offG, const 
         ok = hipMemcpy2DAsync(dst, m * pt, (const uint8_t*)tg->d + offG * pt, tg->n * pt, n * pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess &&
              hipMemcpy2DAsync(dst + n * pt, m * pt, (const uint8_t*)th->d + offH * pt, th->n * pt, n * pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess;
     }
-    ok = ok && hipMemcpy2DAsync(dst + 2 * n * pt, m * pt, conv.p, pt, pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (extra_le) ok = ok && hipMemcpy2DAsync(dst + 2 * n * pt, m * pt, conv.p, pt, pt, (size_t)W1, hipMemcpyDeviceToDevice, s) == hipSuccess;
     // the multiples live in the pinned buffer until the H2D copy has run: wait (this path runs once per proof, not per round)
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     *out = t;
     return BP_OK;
+}
+
+// The verifiers' table of [G[0 .. n) | H[0 .. n)]: the rows of the two vectors' own tables side by side -- 2 W n row copies
+// (201 MB at n = 2^16, c = 16), made on the first verification against these generators and kept on the context.  The key is the pair of
+// table ids (unique per build, so a vector that was freed or precomputed again can never be mistaken) and the row ranges.
+static int bp_internal_gh_table(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, size_t n, const bp_g1table** out) {
+    *out = nullptr;
+    const bp_g1table *tg = G->table ? G->table : G->tview, *th = H->table ? H->table : H->tview;
+    if (!tg || !th || tg->device != ctx->device || th->device != ctx->device || tg->c != th->c || tg->W != th->W) return BP_OK;   // (whatever is kept stays)
+    const size_t offG = G->table ? 0 : G->tview_off, offH = H->table ? 0 : H->tview_off;
+    if (ctx->gh_table && ctx->gh_id[0] == tg->id && ctx->gh_id[1] == th->id && ctx->gh_off[0] == offG && ctx->gh_off[1] == offH && ctx->gh_n == n) {
+        *out = ctx->gh_table;
+        return BP_OK;
+    }
+    if (ctx->gh_table) {                    // other generators: the old table's rows may still be read by an MSM queued on a sibling stream
+        for (bp_ctx* h : ctx->helper) if (h && hipStreamSynchronize(h->stream) != hipSuccess) return BP_ERR_DEVICE;
+        bp_internal_table_free(ctx->gh_table);
+        ctx->gh_table = nullptr;
+    }
+    bp_g1table* t = nullptr;
+    int rc = bp_internal_table_concat(ctx, G, 0, H, 0, n, nullptr, &t);
+    if (rc || !t) return rc;
+    ctx->gh_table = t;
+    ctx->gh_id[0] = tg->id; ctx->gh_id[1] = th->id; ctx->gh_off[0] = offG; ctx->gh_off[1] = offH; ctx->gh_n = n;
+    *out = t;
+    return BP_OK;
+}
+
+template <class C>
+static int msm_extras_gh_impl(bp_ctx* ctx, const void* xpts, const void* xsc, size_t nx, const void* gh_sc, const bp_g1table* T, size_t n, uint8_t* out_le) {
+    using I = Impl<C>;
+    bp_ctx* side = nx ? bp_internal_helper(ctx, 0) : nullptr;
+    if (nx && !side) return BP_ERR_DEVICE;
+    int rc = BP_OK;
+    if (side) {                                  // the other terms first: their (latency-bound) launches fill the gaps of the big pipeline
+        if ((rc = bp_internal_fork(ctx, side))) return rc;
+        rc = I::msm_begin(side, xpts, 0, xsc, 0, nx);
+    }
+    if (rc == BP_OK) rc = I::msm_begin(ctx, T->d, 0, gh_sc, 0, 2 * n, T);
+    bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (side) ok = (hipStreamSynchronize(side->stream) == hipSuccess) && ok;     // both drained whatever happened: the callers' temporaries are in use there
+    ctx->pending = false;
+    if (side) side->pending = false;
+    if (rc) return rc;
+    if (!ok) return BP_ERR_DEVICE;
+    const int ra = ctx->pending_nrec, rb = side ? side->pending_nrec : 0;
+    if (ra + rb > kMaxRecords) return BP_ERR_DEVICE;
+    std::vector<XyzzPacked<C>> rec((size_t)(ra + rb));
+    std::vector<uint16_t> pos((size_t)(ra + rb));
+    memcpy(rec.data(), ctx->host_pinned, (size_t)ra * I::kXyzzBytes);
+    memcpy(pos.data(), ctx->pending_rpos, (size_t)ra * sizeof(uint16_t));
+    if (rb) {
+        memcpy(rec.data() + ra, side->host_pinned, (size_t)rb * I::kXyzzBytes);
+        memcpy(pos.data() + ra, side->pending_rpos, (size_t)rb * sizeof(uint16_t));
+    }
+    I::fold1(ctx, rec.data(), 1, ra + rb, pos.data(), out_le);
+    return BP_OK;
+}
+
+static int gh_table_for(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, size_t n, const bp_g1table** T) {
+    *T = nullptr;
+    const uint32_t lim = ctx->tuning.verify_tables;          // 0 (default): never -- measured slower than the plain MSM on MI355X
+    if (lim < 2 || n < lim || n > G->n || n > H->n || ctx->device_tail || ctx->win_count) return BP_OK;
+    return bp_internal_gh_table(ctx, G, H, n, T);
+}
+int bp_internal_gh_ready(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, size_t n, bool* yes) {
+    const bp_g1table* T = nullptr;
+    int rc = gh_table_for(ctx, G, H, n, &T);
+    *yes = rc == BP_OK && T != nullptr;
+    return rc;
+}
+int bp_internal_msm_extras_gh(bp_ctx* ctx, const void* xpts, const void* xsc, size_t nx, const void* gh_sc, const bp_g1vec* G, const bp_g1vec* H, size_t n,
+                              uint8_t* out_le, bool* done) {
+    *done = false;
+    const bp_g1table* T = nullptr;
+    int rc = gh_table_for(ctx, G, H, n, &T);
+    if (rc || !T) return rc;
+    *done = true;
+    if (ctx->curve == BP_CURVE_BLS12_381) return msm_extras_gh_impl<Bls381>(ctx, xpts, xsc, nx, gh_sc, T, n, out_le);
+    return msm_extras_gh_impl<Bn254>(ctx, xpts, xsc, nx, gh_sc, T, n, out_le);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -989,8 +1091,9 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->fixed_base_table.release();
+    if (ctx->gh_table) { bp_internal_table_free(ctx->gh_table); ctx->gh_table = nullptr; }
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
-                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags}) b->release();
+                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags, &ctx->huge}) b->release();
     if (ctx->pool) { ctx->pool->trim(); ctx->pool->release(); }     // cached blocks go back to the driver now; live handles keep the (empty) pool alive
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -1083,6 +1186,10 @@ int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value) {
     case BP_TUNE_GLV:           // 0 automatic (on where the curve has the split: BLS12-381), 1 off
         if (value > 1) return BP_ERR_ARG;
         ctx->tuning.glv = value == 0;
+        return BP_OK;
+    case BP_TUNE_VERIFY_TABLES: // 0 never (default), else the smallest n (>= 2) whose verification uses the tables
+        if (value == 1 || value > (1L << 30)) return BP_ERR_ARG;
+        ctx->tuning.verify_tables = (uint32_t)value;
         return BP_OK;
     case BP_TUNE_COMPACT_AT:    // 0 automatic, 1 never, else the live length (a power of two whose rounds are single launches) to compact at
         if (value > 1 && (value < 16 || (value & (value - 1)) || 2 * (size_t)value + 1 > kSmallDigitMax)) return BP_ERR_ARG;
@@ -1256,6 +1363,28 @@ int bp_g1vec_drop_table(bp_g1vec* v) {
     if (!v) return BP_ERR_ARG;
     if (v->table) { bp_internal_table_free(v->table); v->table = nullptr; }
     if (v->ctable) { bp_internal_table_free(v->ctable); v->ctable = nullptr; }
+    return BP_OK;
+    });
+}
+
+int bp_ctx_verify_table_info(const bp_ctx* ctx, size_t* n, size_t* bytes) {
+    return bp_guard([&]() -> int {
+    if (!ctx) return BP_ERR_ARG;
+    const bp_g1table* t = ctx->gh_table;
+    if (n) *n = t ? ctx->gh_n : 0;
+    if (bytes) *bytes = t ? (size_t)t->W * t->n * 2 * (size_t)fp_bytes_of(ctx->curve) : 0;
+    return BP_OK;
+    });
+}
+
+int bp_ctx_drop_verify_table(bp_ctx* ctx) {
+    return bp_guard([&]() -> int {
+    if (!ctx) return BP_ERR_ARG;
+    if (!ctx->gh_table) return BP_OK;
+    int rc = set_device(ctx); if (rc) return rc;
+    for (bp_ctx* h : ctx->helper) if (h) HIPCHK(hipStreamSynchronize(h->stream));
+    bp_internal_table_free(ctx->gh_table);          // back to the pool in the order of ctx->stream, where its MSMs ran
+    ctx->gh_table = nullptr;
     return BP_OK;
     });
 }

@@ -548,8 +548,13 @@ struct Ipp {
         int rc = verification_scalars(t, L_le, R_le, lg_n, n, ch, ch_inv);              // :218
         if (rc) return rc;
         size_t m = 1 + 2 * n + 2 * lg_n;
+        // G and H precomputed: their terms run over the window tables, [Q | L | R] as a small MSM beside them
+        bool tabled = false;
+        if ((rc = bp_internal_gh_ready(ctx, G, H, n, &tabled))) return rc;
+        const size_t nx = 1 + 2 * lg_n;
         PoolBlock b_pts, b_sc, b_chd, b_raw;      // recycled through the context's pool (no hipMalloc / hipFree per proof)
-        if (!b_pts.alloc(ctx, m * kPt) || !b_sc.alloc(ctx, m * 32) || !b_chd.alloc(ctx, (2 * lg_n + 1) * 32) || !b_raw.alloc(ctx, (2 * lg_n + 1) * 2 * kFb))
+        if (!b_pts.alloc(ctx, (tabled ? nx : m) * kPt) || !b_sc.alloc(ctx, (m + (tabled ? nx : 0)) * 32) || !b_chd.alloc(ctx, (2 * lg_n + 1) * 32) ||
+            !b_raw.alloc(ctx, (2 * lg_n + 1) * 2 * kFb))
             return BP_ERR_DEVICE;
         void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
         auto cleanup = [&]() {};
@@ -579,6 +584,24 @@ struct Ipp {
                   hipMemcpyAsync(sc, ends.data(), 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   (lg_n == 0 || hipMemcpyAsync((uint8_t*)sc + (1 + 2 * n) * 32, ends.data() + 1, 2 * lg_n * 32, hipMemcpyHostToDevice, s) == hipSuccess);
         if (!ok) { cleanup(); return BP_ERR_DEVICE; }
+        if (tabled) {
+            // [Q | L | R] -> pts[0 .. nx), their scalars -> sc[m .. m + nx); the generators' scalars -> sc[1 .. 1 + 2n)
+            void* xs = (uint8_t*)sc + m * 32;
+            if (hipMemcpyAsync(xs, ends.data(), nx * 32, hipMemcpyHostToDevice, s) != hipSuccess) return BP_ERR_DEVICE;
+            hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(nx)), dim3(kBlock), 0, s, (const uint32_t*)raw, nx, (AffPacked<C>*)pts, flag);
+            if (hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return BP_ERR_DEVICE;
+            hipLaunchKernelGGL(k_ipp_verify_terms<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
+                               (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, (const ScalarWords*)chd, (const ScalarWords*)chd + lg_n, (int)lg_n,
+                               fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)nullptr, (ScalarWords*)sc);
+            if (hipGetLastError() != hipSuccess) return BP_ERR_DEVICE;
+            uint8_t expect[2 * kFb];
+            bool done = false;
+            rc = bp_internal_msm_extras_gh(ctx, pts, xs, nx, (const uint8_t*)sc + 32, G, H, n, expect, &done);   // synchronises both streams
+            if (rc) return rc;
+            if (!done) return BP_ERR_DEVICE;                                                // bp_internal_gh_ready said yes
+            if (host_flag) return BP_ERR_VERIFY;
+            return memcmp(expect, P_le, 2 * kFb) == 0 ? BP_OK : BP_ERR_VERIFY;
+        }
         // Q -> pts[0]; L,R -> pts[1+2n ..]
         hipLaunchKernelGGL(k_points_to_resident<C>, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)raw, (size_t)1, (AffPacked<C>*)pts, flag);
         if (lg_n)
@@ -637,8 +660,10 @@ struct Ipp {
             memcpy(rw + (1 + 2 * lg_n) * 2 * kFb, pr.P_le, 2 * kFb);
         }
         const size_t nch = hch.size();
+        bool tabled = false;
+        { int rct = bp_internal_gh_ready(ctx, G, H, n, &tabled); if (rct) return rct; }
         PoolBlock b_pts, b_sc, b_chd, b_raw;
-        if (!b_pts.alloc(ctx, total * kPt) || !b_sc.alloc(ctx, total * 32) || !b_chd.alloc(ctx, (2 * nch + 2 * m) * 32) || !b_raw.alloc(ctx, hraw.size()))
+        if (!b_pts.alloc(ctx, (tabled ? m * per : total) * kPt) || !b_sc.alloc(ctx, total * 32) || !b_chd.alloc(ctx, (2 * nch + 2 * m) * 32) || !b_raw.alloc(ctx, hraw.size()))
             return BP_ERR_DEVICE;
         void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
         auto cleanup = [&]() {};
@@ -655,14 +680,22 @@ struct Ipp {
                   hipMemcpyAsync(raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync((uint8_t*)sc + 2 * n * 32, tail.data(), m * per * 32, hipMemcpyHostToDevice, s) == hipSuccess;
         if (!ok) { cleanup(); return BP_ERR_DEVICE; }
-        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(m * per)), dim3(kBlock), 0, s, (const uint32_t*)raw, m * per, (AffPacked<C>*)pts + 2 * n, flag);
+        AffPacked<C>* xp = (AffPacked<C>*)pts + (tabled ? 0 : 2 * n);      // the proofs' own points: alone in the buffer when [G | H] run over their tables
+        hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(m * per)), dim3(kBlock), 0, s, (const uint32_t*)raw, m * per, xp, flag);
         if (hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return BP_ERR_DEVICE;
         hipLaunchKernelGGL(k_ipp_verify_terms_batch<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
-                           (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, d_ch, d_chi, d_wa, d_wb, (int)lg_n, m, n, (AffPacked<C>*)pts,
-                           (ScalarWords*)sc);
+                           (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, d_ch, d_chi, d_wa, d_wb, (int)lg_n, m, n,
+                           tabled ? (AffPacked<C>*)nullptr : (AffPacked<C>*)pts, (ScalarWords*)sc);
         if (hipGetLastError() != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
         uint8_t got[2 * kFb];
-        int rc = bp_internal_msm(ctx, pts, sc, total, got);
+        int rc;
+        if (tabled) {
+            bool done = false;
+            rc = bp_internal_msm_extras_gh(ctx, xp, (const uint8_t*)sc + 2 * n * 32, m * per, sc, G, H, n, got, &done);
+            if (rc == BP_OK && !done) rc = BP_ERR_DEVICE;
+        } else {
+            rc = bp_internal_msm(ctx, pts, sc, total, got);
+        }
         if (hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : BP_ERR_DEVICE;
         if (rc) return rc;
         if (host_flag) return BP_ERR_VERIFY;

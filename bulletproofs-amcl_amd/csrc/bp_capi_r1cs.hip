@@ -379,29 +379,36 @@ struct R1cs {
         const Fe<F> r = fr_in<F>(r_le32);                                                                      // :392
         const Fe<F> x2 = fe_sqr(x), x3 = fe_mul(x2, x);
         const Fe<F> tx = fr_in<F>(S), txb = fr_in<F>(S + 32), eb = fr_in<F>(S + 64);
-        // scalars and points in the reference's order (:409-446): A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1.. | g h | G | H | L | R
-        const size_t head = 6 + m + 5 + 2, total = head + 2 * pn + 2 * lg;
+        // The reference's terms (:409-446: A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1.. | g h | G | H | L | R) in the order
+        //   [A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1.. | g h | L | R] ++ [G | H]
+        // (a sum does not depend on it): the first nx = head + 2 lg points come from the proof and the caller, one upload; the generators are
+        // resident, and when both carry a window table their part runs over the tables without being copied at all.
+        const size_t head = 6 + m + 5 + 2, nx = head + 2 * lg, total = nx + 2 * pn;
+        bool tabled = false;
+        RC(bp_internal_gh_ready(ctx, G, H, pn, &tabled));
         bp_frvec* sc = nullptr;
         bp_g1vec* pts = nullptr;
         RC(bp_frvec_alloc(ctx, total, &sc));
         T.keep(sc);
-        RC(bp_g1vec_alloc(ctx, total, &pts));
-        T.keep(pts);
-        std::vector<uint8_t> hs(6 * 32), ts(7 * 32);
+        std::vector<uint8_t> xs(nx * 32);
         const Fe<F> hv[6] = {x, x2, x3, fe_mul(u, x), fe_mul(u, x2), fe_mul(u, x3)};
-        for (int k = 0; k < 6; k++) fr_out<F>(hv[k], hs.data() + 32 * k);
+        for (int k = 0; k < 6; k++) fr_out<F>(hv[k], xs.data() + 32 * k);
+        uint8_t* ts = xs.data() + (6 + m) * 32;
         Fe<F> rx = fe_mul(r, x);
-        fr_out<F>(rx, ts.data());                                                                              // r x
+        fr_out<F>(rx, ts);                                                                                     // r x
         Fe<F> acc = fe_mul(r, x3);
-        for (int k = 1; k < 5; k++) { fr_out<F>(acc, ts.data() + 32 * k); acc = fe_mul(acc, x); }              // r x^3 .. r x^6
+        for (int k = 1; k < 5; k++) { fr_out<F>(acc, ts + 32 * k); acc = fe_mul(acc, x); }                     // r x^3 .. r x^6
         const Fe<F> wg = fe_add(fe_mul(wch, fe_sub(tx, fe_mul(a, b))), fe_mul(r, fe_sub(fe_mul(x2, fe_add(wc, delta)), tx)));   // :422
         const Fe<F> ph = fe_neg(fe_add(eb, fe_mul(r, txb)));                                                   // :425
-        fr_out<F>(wg, ts.data() + 5 * 32);
-        fr_out<F>(ph, ts.data() + 6 * 32);
-        bp_frvec *d_hs = nullptr, *d_ts = nullptr;
-        RC(upload_scalars(ctx, T, hs, &d_hs));
-        RC(upload_scalars(ctx, T, ts, &d_ts));
-        RC(bp_frvec_copy(ctx, sc, 0, d_hs, 0, 6));
+        fr_out<F>(wg, ts + 5 * 32);
+        fr_out<F>(ph, ts + 6 * 32);
+        if (lg) {
+            memcpy(xs.data() + head * 32, usq.data(), lg * 32);
+            memcpy(xs.data() + (head + lg) * 32, uisq.data(), lg * 32);
+        }
+        bp_frvec* d_xs = nullptr;
+        RC(upload_scalars(ctx, T, xs, &d_xs));                                                                 // (the V slots are overwritten below)
+        RC(bp_frvec_copy(ctx, sc, 0, d_xs, 0, nx));
         if (m) {
             uint8_t rx2[32];
             fr_out<F>(fe_mul(r, x2), rx2);
@@ -410,41 +417,33 @@ struct R1cs {
             T.keep(wvs);
             RC(bp_frvec_copy(ctx, sc, 6, wvs, 0, m));
         }
-        RC(bp_frvec_copy(ctx, sc, 6 + m, d_ts, 0, 7));
-        RC(bp_frvec_copy(ctx, sc, head, g_sc, 0, pn));
-        RC(bp_frvec_copy(ctx, sc, head + pn, h_sc, 0, pn));
-        if (lg) {
-            std::vector<uint8_t> us(2 * lg * 32);
-            memcpy(us.data(), usq.data(), lg * 32);
-            memcpy(us.data() + lg * 32, uisq.data(), lg * 32);
-            bp_frvec* d_us = nullptr;
-            RC(upload_scalars(ctx, T, us, &d_us));
-            RC(bp_frvec_copy(ctx, sc, head + 2 * pn, d_us, 0, 2 * lg));
-        }
-        std::vector<uint8_t> hp(head * pb);
+        RC(bp_frvec_copy(ctx, sc, nx, g_sc, 0, pn));
+        RC(bp_frvec_copy(ctx, sc, nx + pn, h_sc, 0, pn));
+        std::vector<uint8_t> hp(nx * pb);
         memcpy(hp.data(), P, 6 * pb);
         if (m) memcpy(hp.data() + 6 * pb, V_le, m * pb);
         memcpy(hp.data() + (6 + m) * pb, P + 6 * pb, 5 * pb);
         memcpy(hp.data() + (11 + m) * pb, g_le, pb);
         memcpy(hp.data() + (12 + m) * pb, h_le, pb);
-        bp_g1vec* d_hp = nullptr;
-        RCV(bp_g1vec_upload(ctx, hp.data(), head, BP_FMT_LE, &d_hp));
-        T.keep(d_hp);
-        hipStream_t s = ctx->stream;
-        HIPCHK(hipMemcpyAsync(pts->d, d_hp->d, head * row, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + head * row, G->d, pn * row, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (head + pn) * row, H->d, pn * row, hipMemcpyDeviceToDevice, s));
         if (lg) {
-            std::vector<uint8_t> lr(2 * lg * pb);
-            memcpy(lr.data(), Lp, lg * pb);
-            memcpy(lr.data() + lg * pb, Rp, lg * pb);
-            bp_g1vec* d_lr = nullptr;
-            RCV(bp_g1vec_upload(ctx, lr.data(), 2 * lg, BP_FMT_LE, &d_lr));
-            T.keep(d_lr);
-            HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (head + 2 * pn) * row, d_lr->d, 2 * lg * row, hipMemcpyDeviceToDevice, s));
+            memcpy(hp.data() + head * pb, Lp, lg * pb);
+            memcpy(hp.data() + (head + lg) * pb, Rp, lg * pb);
         }
+        bp_g1vec* d_hp = nullptr;
+        RCV(bp_g1vec_upload(ctx, hp.data(), nx, BP_FMT_LE, &d_hp));
+        T.keep(d_hp);
         uint8_t res[pb];
-        RC(bp_msm_g1(ctx, pts, sc, res));                                                                      // :448
+        bool done = false;
+        if (tabled) RC(bp_internal_msm_extras_gh(ctx, d_hp->d, sc->d, nx, (const uint8_t*)sc->d + nx * 32, G, H, pn, res, &done));
+        if (!done) {
+            RC(bp_g1vec_alloc(ctx, total, &pts));
+            T.keep(pts);
+            hipStream_t s = ctx->stream;
+            HIPCHK(hipMemcpyAsync(pts->d, d_hp->d, nx * row, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + nx * row, G->d, pn * row, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (nx + pn) * row, H->d, pn * row, hipMemcpyDeviceToDevice, s));
+            RC(bp_msm_g1(ctx, pts, sc, res));                                                                  // :448
+        }
         for (size_t k = 0; k < pb; k++) if (res[k]) return BP_ERR_VERIFY;                                       // !res.is_identity(), :449-451
         return BP_OK;
     }

@@ -125,6 +125,7 @@ struct bp_tuning {
     bool small_msm = true;      // single-launch path for n <= 512
     uint32_t compact_at = 0;    // inner-product prover: live length at which the folded generators are materialised (0 automatic, 1 never)
     bool glv = true;            // ... and whether that compaction (and the rounds after it) split the scalars with the GLV endomorphism (BLS12-381)
+    uint32_t verify_tables = 0; // verifiers: generators per vector from which the [G | H] part of the check runs over the vectors' window tables (0 = never)
 };
 
 struct bp_ctx {
@@ -144,7 +145,7 @@ struct bp_ctx {
     // MSM workspace
     DevBuf fixed_base_table;            // d * 2^(4j) * G, built on first use (bp_g1vec_fixed_base_mul)
     bool fixed_base_ready = false;
-    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch;
+    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch, huge;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     void* stage = nullptr;              // page-locked ring for small host -> device copies of LIBRARY-made data that must not wait for the
@@ -163,6 +164,11 @@ struct bp_ctx {
     // geometry of the MSM queued by bp_msm_g1_begin (consumed by _end; bp_ctx_set_window_bits in between cannot disturb it)
     int pending_nrec = 0;
     uint16_t pending_rpos[bp::kMaxRecords] = {};
+    // the verifiers' window table of [G[offG .. +n) | H[offH .. +n)] (bp_internal_gh_table): built from the two vectors' tables on the first
+    // verification and kept until other generators (other table ids / ranges) are verified against or the context is destroyed
+    struct bp_g1table* gh_table = nullptr;
+    uint64_t gh_id[2] = {0, 0};
+    size_t gh_off[2] = {0, 0}, gh_n = 0;
 };
 
 inline int DevBuf::reserve(bp_ctx* ctx, size_t bytes) {
@@ -243,6 +249,7 @@ struct bp_g1table {
     bool glv = false;        // digits only: the table of a GLV-split set (bp_compact.cuh: k_glv_table_rows; rows[((m - 1) * 2 + half) * n + t], 16 multiples):
                              // only k_small_msm_glv reads it; the generic MSM paths ignore such a table
     int K = 1;               // digits only: sub-rows per point (compaction table: K = 4, rows[(m - 1) * K * n + k * n + i] = m 2^(64 k) P_i)
+    uint64_t id = 0;         // window tables: unique per build (never reused), so that a cache keyed on it cannot mistake a rebuilt table for the old one
 };
 extern "C" void bp_internal_table_free(bp_g1table* t);
 int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_g1table** out);
@@ -294,6 +301,14 @@ int bp_internal_set_device(const bp_ctx* ctx);
 // canonicity check and without waiting for the stream (the bytes are staged in the context's page-locked ring)
 extern "C" int bp_internal_frvec_upload_trusted(bp_ctx* ctx, const uint8_t* le32, size_t n, bp_frvec** out);
 // a few two-term commitments k1 g + k2 h on the host (bp_capi.hip)
+// The verifiers' single check  out = <xsc, xpts> + <gh_sc, [G[0 .. n) | H[0 .. n)]>  with the [G | H] part over the vectors' window tables
+// (merged-window pipeline on ctx's stream) and the nx other terms (proof points, commitments) as their own MSM on a sibling stream, one
+// host fold over both record sets.  *done = false (and nothing queued) when BP_TUNE_VERIFY_TABLES is off (the default) or n is below its
+// limit, when G or H has no table, or the widths differ: the caller then runs the plain MSM over the concatenated vector.
+// whether bp_internal_msm_extras_gh will run over the tables for these generators (builds / finds the context's [G | H] table)
+int bp_internal_gh_ready(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, size_t n, bool* yes);
+int bp_internal_msm_extras_gh(bp_ctx* ctx, const void* xpts, const void* xsc, size_t nx, const void* gh_sc, const bp_g1vec* G, const bp_g1vec* H, size_t n,
+                              uint8_t* out_le, bool* done);
 int bp_internal_host_mul2(bp_ctx* ctx, const uint8_t* g_le, const uint8_t* h_le, const uint8_t* k1_le32, const uint8_t* k2_le32, int count, uint8_t* const* out_le);
 // building blocks of the sharded inner-product argument (bp_capi.hip)
 int bp_internal_pair_width(bp_ctx* ctx, size_t n, size_t nnz);

@@ -609,8 +609,10 @@ __global__ void __launch_bounds__(kBlock) k_ipp_verify_terms(const AffPacked<C>*
     // s, sinv are Montgomery; (a_mont * s) is Montgomery; times canonical factor -> canonical
     fr_store<F>(sc, 1 + i, fe_mul(fe_mul(fe_unpack_words<F>(a_mont.w), s), fr_load<F>(gf, i)));
     fr_store<F>(sc, 1 + n + i, fe_mul(fe_mul(fe_unpack_words<F>(b_mont.w), sinv), fr_load<F>(hf, i)));
-    pts[1 + i] = G[i];
-    pts[1 + n + i] = H[i];
+    if (pts) {                               // NULL: the MSM runs over the generators' own tables (bp_internal_msm_extras_gh), scalars only
+        pts[1 + i] = G[i];
+        pts[1 + n + i] = H[i];
+    }
 }
 
 // Batch verification of m proofs over the SAME generators (the random-linear-combination argument of
@@ -643,8 +645,10 @@ __global__ void __launch_bounds__(kBlock) k_ipp_verify_terms_batch(const AffPack
     // Montgomery accumulators times canonical factors -> canonical scalars
     fr_store<F>(sc, i, fe_mul(gacc, fr_load<F>(gf, i)));
     fr_store<F>(sc, n + i, fe_mul(hacc, fr_load<F>(hf, i)));
-    pts[i] = G[i];
-    pts[n + i] = H[i];
+    if (pts) {                               // NULL: as in k_ipp_verify_terms
+        pts[i] = G[i];
+        pts[n + i] = H[i];
+    }
 }
 
 }  // namespace bp

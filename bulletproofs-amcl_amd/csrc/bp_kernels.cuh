@@ -212,14 +212,23 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
 // (Structured scalars make ONE coarse bin huge -- bit vectors put half of all records into one bucket -- and its block then streams
 // 2^19 records alone: 0.89 ms at n = 2^20.  Peeling the wave's most common key off the LDS counters (one atomic per wave for it) was
 // measured in round 3: no gain for bits (the block is bound by its own load / store stream, not by the counter), 2x slower for a
-// huge bin with 255 live buckets (8-bit scalars).  The fix is several blocks per huge bin, i.e. a count / place pair of kernels.)
+// huge bin with 255 live buckets (8-bit scalars).  The fix is several blocks per huge bin, i.e. a count / place pair of kernels:
+// k_fine_huge_count / k_fine_huge_place below, round 4.)
 // grid = (128, W); block (bin, w) owns the elements [tile_off[row * ntiles], tile_off[(row + 1) * ntiles]) of its
 // coarse bin (row = hoff[w] + bin; `total` closes the last row).  Two streaming passes over them: fine histogram,
 // then placement.  Writes start[g] / end[g] for its 2^fbits buckets and idx[] (point index + sign bit).
+// A coarse bin with more than kHugeMin records (round 4) is not streamed by its one block: k_fine_place cuts it into slices
+// of kHugeSlice records, and the k_fine_huge_count / _place pair below runs a block per slice (per-slice histograms in HBM; the bin's
+// bucket bounds from their sums, a slice's cursors from the slices before it).
+struct HugeSlice { uint32_t bin, w, lo, hi, first, count, bin_lo, pad; };   // records [lo, hi) of coarse bin `bin` of window w; the bin's slices are first .. first + count - 1
+constexpr uint32_t kHugeSlice = 8192;
+constexpr uint32_t kHugeMin = 4 * kHugeSlice;
+
 static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __restrict__ tmp_rec, WinTab tab, uint32_t ntiles, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ total,
                                                              uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx, int w0,
-                                                             uint32_t* __restrict__ nonempty) {
+                                                             uint32_t* __restrict__ nonempty, HugeSlice* __restrict__ slices, uint32_t* __restrict__ nslices) {
     __shared__ uint32_t lh[kBlock], lscan[kBlock / 64];
+    __shared__ uint32_t s_first;
     const int w = w0 + (int)blockIdx.y;
     const uint32_t nbins = tab.hoff[w + 1] - tab.hoff[w];
     if (blockIdx.x >= nbins) return;
@@ -228,6 +237,16 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
     const uint32_t lo = tile_off[(size_t)row * ntiles];
     const uint32_t hi = row + 1 < rows ? tile_off[(size_t)(row + 1) * ntiles] : *total;
     const uint32_t fmask = (1u << fb) - 1;
+    if (slices && hi - lo > kHugeMin) {                      // (block-uniform) hand the bin to the slice kernels
+        const uint32_t cnt = (hi - lo + kHugeSlice - 1) / kHugeSlice;
+        if (threadIdx.x == 0) s_first = atomicAdd(nslices, cnt);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) {
+            const uint32_t a = lo + k * kHugeSlice;
+            slices[s_first + k] = HugeSlice{blockIdx.x, (uint32_t)w, a, a + kHugeSlice < hi ? a + kHugeSlice : hi, s_first, cnt, lo, 0u};
+        }
+        return;
+    }
     lh[threadIdx.x] = 0;
     __syncthreads();
     // kFineBatch records per lane are loaded before any of them is used: the loop is otherwise a chain of (load, LDS atomic) pairs
@@ -269,6 +288,79 @@ static __global__ void __launch_bounds__(kBlock) k_fine_place(const uint2* __res
                 idx[pos] = rec[u].x | (d < 0 ? 0x80000000u : 0u);
             }
         }
+    }
+}
+
+// grid-stride over the slices k_fine_place listed: hist[s * kBlock + key] = records of slice s with fine key `key`
+static __global__ void __launch_bounds__(kBlock) k_fine_huge_count(const uint2* __restrict__ tmp_rec, WinTab tab, const HugeSlice* __restrict__ slices,
+                                                                  const uint32_t* __restrict__ nslices, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[kBlock];
+    const uint32_t ns = *nslices;
+    for (uint32_t s = blockIdx.x; s < ns; s += gridDim.x) {
+        const HugeSlice sl = slices[s];
+        const uint32_t fmask = (1u << tab.fbits[sl.w]) - 1;
+        lh[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t j0 = sl.lo + threadIdx.x; j0 < sl.hi; j0 += kFineBatch * kBlock) {
+            int dd[kFineBatch];
+#pragma unroll
+            for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; dd[u] = j < sl.hi ? (int)tmp_rec[j].y : 0; }
+#pragma unroll
+            for (int u = 0; u < kFineBatch; u++) {
+                const int d = dd[u];
+                if (d != 0) atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+            }
+        }
+        __syncthreads();
+        hist[(size_t)s * kBlock + threadIdx.x] = lh[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// ... and the placement: bucket bounds of the bin (written by its first slice) and this slice's cursors from the per-slice histograms
+static __global__ void __launch_bounds__(kBlock) k_fine_huge_place(const uint2* __restrict__ tmp_rec, WinTab tab, const HugeSlice* __restrict__ slices,
+                                                                  const uint32_t* __restrict__ nslices, const uint32_t* __restrict__ hist,
+                                                                  uint32_t* __restrict__ start, uint32_t* __restrict__ end, uint32_t* __restrict__ idx,
+                                                                  uint32_t* __restrict__ nonempty) {
+    __shared__ uint32_t lh[kBlock], lscan[kBlock / 64];
+    const uint32_t ns = *nslices;
+    for (uint32_t s = blockIdx.x; s < ns; s += gridDim.x) {
+        const HugeSlice sl = slices[s];
+        const int fb = tab.fbits[sl.w];
+        const uint32_t fmask = (1u << fb) - 1;
+        uint32_t tot = 0, before = 0;
+        for (uint32_t k = 0; k < sl.count; k++) {
+            const uint32_t v = hist[(size_t)(sl.first + k) * kBlock + threadIdx.x];
+            tot += v;
+            if (sl.first + k < s) before += v;
+        }
+        uint32_t all;
+        const uint32_t ex = block_exclusive_scan(tot, lscan, all) + sl.bin_lo;
+        if (s == sl.first) {                                 // (block-uniform)
+            if (threadIdx.x <= fmask) {
+                const uint32_t g = tab.boff[sl.w] + (sl.bin << fb) + threadIdx.x;
+                start[g] = ex;
+                end[g] = ex + tot;
+            }
+            const int ne = __syncthreads_count(threadIdx.x <= fmask && tot != 0);
+            if (threadIdx.x == 0 && ne) atomicAdd(&nonempty[sl.w], (uint32_t)ne);
+        }
+        lh[threadIdx.x] = ex + before;
+        __syncthreads();
+        for (uint32_t j0 = sl.lo + threadIdx.x; j0 < sl.hi; j0 += kFineBatch * kBlock) {
+            uint2 rec[kFineBatch];
+#pragma unroll
+            for (int u = 0; u < kFineBatch; u++) { uint32_t j = j0 + u * kBlock; rec[u] = j < sl.hi ? tmp_rec[j] : make_uint2(0u, 0u); }
+#pragma unroll
+            for (int u = 0; u < kFineBatch; u++) {
+                const int d = (int)rec[u].y;
+                if (d != 0) {
+                    uint32_t pos = atomicAdd(&lh[((uint32_t)(d < 0 ? -d : d) - 1) & fmask], 1u);
+                    idx[pos] = rec[u].x | (d < 0 ? 0x80000000u : 0u);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

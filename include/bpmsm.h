@@ -102,6 +102,13 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
                                * every round (/root/reference src/ipp.rs:181-188 folds G, H every round; this is that fold, done once).  0 = automatic
                                * (4096, for proofs of >= 8192 generators), 1 = never, else a power of two in [16, 4096]: every longer proof compacts
                                * there.  Proof bytes do not depend on it. */
+#define BP_TUNE_VERIFY_TABLES 8 /* verifiers (bp_ipp_verify, bp_ipp_verify_batch, bp_r1cs_verify*): n >= 2 = when BOTH generator vectors carry a window table
+                               * of the same width (bp_g1vec_precompute) and the statement has at least n generators per vector, the [G | H] part of the
+                               * verification MSM (/root/reference src/ipp.rs:244-253, src/r1cs/verifier.rs:431-451) runs over those tables, the proof's
+                               * own points as a second, small MSM beside it; the context then keeps the side-by-side table of the generators it last
+                               * verified against (2 W n rows) until bp_ctx_drop_verify_table / bp_ctx_destroy.  0 (default) = never: on MI355X the
+                               * plain MSM is as fast or faster (its 16 passes over 2n points stay in L2, the table's rows do not: IPP 2^16 verify 1.09
+                               * against 1.13 ms).  Accept / reject do not depend on it. */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, long value);
 /* Vectors and temporaries come from a per-context caching pool (hipMalloc / hipFree per proof cost more than the kernels
  * of a small proof; blocks are recycled in stream order).  bp_ctx_trim returns the cached blocks to the driver. */
@@ -143,6 +150,10 @@ int bp_g1vec_precompute(bp_ctx* ctx, bp_g1vec* v, int window_bits);
 int bp_g1vec_drop_table(bp_g1vec* v);
 /* window width, number of windows and bytes of the vector's tables (window multiples + compaction table; all 0 when it has none) */
 int bp_g1vec_table_info(const bp_g1vec* v, int* window_bits, int* windows, size_t* bytes);
+/* The side-by-side table [G | H] a context keeps for its verifiers (BP_TUNE_VERIFY_TABLES): generators per vector and bytes held (zeros when
+ * there is none), and giving it back to the pool before the context goes (the next verification over tables rebuilds it). */
+int bp_ctx_verify_table_info(const bp_ctx* ctx, size_t* n, size_t* bytes);
+int bp_ctx_drop_verify_table(bp_ctx* ctx);
 /* out[i] = k[i] * G.  Batched form of `&G1::generator() * &FieldElement` (src/utils/mod.rs:34); used to build
  * synthetic generator vectors on the device. */
 int bp_g1vec_fixed_base_mul(bp_ctx* ctx, const bp_frvec* k, bp_g1vec** out);

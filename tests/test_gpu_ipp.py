@@ -536,6 +536,97 @@ def _random_constraint_system(rng, r, nq, n, m, hub=None):
     return cons
 
 
+@pytest.mark.parametrize("name,n,c,lim", [("bls12_381", 64, 8, 16), ("bn254", 256, 16, 2), ("bls12_381", 4096, 16, 4096), ("bn254", 8192, 13, 4096)])
+def test_ipp_verify_over_generator_tables(bp, name, n, c, lim):
+    """VERDICT r3 #8 (verify_ipp, /root/reference src/ipp.rs:204-260): with window tables on G and H the verifier's [G | H] terms run over
+    the tables (a side-by-side table the context keeps) and [Q | L | R] as a small MSM beside them.  Same accept / reject matrix as the
+    plain path, single and batched, for a prefix of longer generator vectors, after the tables change, and when they cannot be used."""
+    cid = bp.CURVE_IDS[name]
+    ctx = bp.Context(cid, 0)                                    # its own context: the knob and the kept table are per context
+    with pytest.raises(bp.ArgError):
+        ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 1)
+    Gv, Hv, Q, Gf, Hf, a, b = make_instance(bp, ctx, n, 77000 + n, unit_gf=False)
+    label = b"verify over tables"
+    proof = bp.IPP.create_ipp(ctx, bp.Transcript(label), Q, Gf, Hf, Gv, Hv, a, b)
+    P = commitment_P(bp, ctx, Gv, Hv, Q, Gf, Hf, a, b)
+    pb = ctx.point_bytes
+    ver = lambda **kw: bp.IPP.verify_ipp(ctx, kw.get("n", n), bp.Transcript(label), kw.get("Gf", Gf), kw.get("Hf", Hf), kw.get("P", P), kw.get("Q", Q),
+                                         kw.get("G", Gv), kw.get("H", Hv), kw.get("a", proof.a), kw.get("b", proof.b), kw.get("L", proof.L), kw.get("R", proof.R))
+    ver()
+    Gv.precompute(c)
+    Hv.precompute(c)
+    ver()
+    assert ctx.verify_table_info() == (0, 0)                    # off by default: the plain path, tables or not
+    ctx.set_tuning(bp.TUNE_VERIFY_TABLES, lim)
+    after_plain = bp.Transcript(label)
+    bp.IPP.verify_ipp(ctx, n, after_plain, Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+    kept = ctx.verify_table_info()
+    assert kept == (n, Gv.table_info()[1] * 2 * n * pb), kept   # W x 2n rows
+    plain_t = bp.Transcript(label)
+    ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 0)                    # off again: same verdict, same transcript state
+    bp.IPP.verify_ipp(ctx, n, plain_t, Gf, Hf, P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+    assert plain_t.challenge_bytes(b"after", 32) == after_plain.challenge_bytes(b"after", 32)
+    ctx.set_tuning(bp.TUNE_VERIFY_TABLES, lim)
+    assert O.ipp_verify(cid, O.Transcript(label), n, Gf.to_bytes(), Hf.to_bytes(), P, Q, Gv.to_bytes(), Hv.to_bytes(), proof.a, proof.b, proof.L, proof.R,
+                        proof.lg_n) == 0
+
+    def bump(x):
+        return ((int.from_bytes(x, "little") + 1) % ctx.r).to_bytes(32, "little")
+
+    gen = O.generator(cid)
+    off_curve = gen[:pb - 1] + bytes([gen[pb - 1] ^ 1])
+    for kw in ({"a": bump(proof.a)}, {"b": bump(proof.b)}, {"P": gen}, {"Q": gen}, {"L": gen + proof.L[pb:]}, {"R": proof.R[:-pb] + gen},
+               {"L": off_curve + proof.L[pb:]}, {"Q": off_curve}):
+        with pytest.raises((bp.VerificationError, bp.ArgError)):
+            ver(**kw)
+    ver()                                                       # and the kept table is still good
+    # batched over the same tables: accept iff each verifies
+    items = [(label, P, Q, proof)]
+    for j in range(2):
+        a2 = bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, 77100 + j, n), n)
+        b2 = bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, 77200 + j, n), n)
+        Q2 = O.g1_mul(cid, O.random_scalars(cid, 77300 + j, 1), gen)
+        pr2 = bp.IPP.create_ipp(ctx, bp.Transcript(b"b%d" % j), Q2, Gf, Hf, Gv, Hv, a2, b2)
+        items.append((b"b%d" % j, commitment_P(bp, ctx, Gv, Hv, Q2, Gf, Hf, a2, b2), Q2, pr2))
+    refs = lambda bad=None: [(bp.Transcript(lb), Pj, Qj, bump(pr.a) if bad == k else pr.a, pr.b, pr.L, pr.R) for k, (lb, Pj, Qj, pr) in enumerate(items)]
+    bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, refs())
+    for k in range(3):
+        with pytest.raises(bp.VerificationError):
+            bp.IPP.verify_batch(ctx, n, Gf, Hf, Gv, Hv, refs(k))
+    # a proof over the first half of the generators, verified against the long (precomputed) vectors
+    h = n // 2
+    if h >= lim:
+        gb, hb = Gv.to_bytes(), Hv.to_bytes()
+        G2, H2 = bp.G1Vector.from_bytes(ctx, gb[:h * pb], h), bp.G1Vector.from_bytes(ctx, hb[:h * pb], h)
+        fh = lambda v: bp.FieldElementVector.from_bytes(ctx, v.to_bytes()[:h * 32], h)
+        pr = bp.IPP.create_ipp(ctx, bp.Transcript(label), Q, fh(Gf), fh(Hf), G2, H2, fh(a), fh(b))
+        Ph = commitment_P(bp, ctx, G2, H2, Q, fh(Gf), fh(Hf), fh(a), fh(b))
+        ver(n=h, Gf=fh(Gf), Hf=fh(Hf), P=Ph, a=pr.a, b=pr.b, L=pr.L, R=pr.R)
+        assert ctx.verify_table_info()[0] == h                  # the kept table follows the generators last verified against
+        with pytest.raises(bp.VerificationError):
+            ver(n=h, Gf=fh(Gf), Hf=fh(Hf), P=Ph, a=bump(pr.a), b=pr.b, L=pr.L, R=pr.R)
+        ver()
+        assert ctx.verify_table_info()[0] == n
+    # the tables are rebuilt (new rows, same points): the kept table must not be mistaken for the new vectors'
+    Gv.precompute(c)
+    ver()
+    with pytest.raises(bp.VerificationError):
+        ver(a=bump(proof.a))
+    # widths differ: no side-by-side table, the plain path decides
+    Hv.precompute(c - 1)
+    ver()
+    with pytest.raises(bp.VerificationError):
+        ver(b=bump(proof.b))
+    Hv.precompute(c)
+    ver()
+    assert ctx.verify_table_info()[0] == n
+    ctx.drop_verify_table()
+    assert ctx.verify_table_info() == (0, 0)
+    ver()
+    Gv.free(); Hv.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", CURVES)
 @pytest.mark.parametrize("nq,n,m", [(0, 4, 1), (1, 1, 1), (37, 5, 3), (700, 64, 8), (5000, 300, 0)])
 def test_r1cs_flattened_constraints(bp, ctxs, name, nq, n, m):

@@ -288,15 +288,31 @@ def test_msm_heavy_skew_2e18(bp, ctxs, name):
     import random
     rnd = random.Random(5)
     vals16 = [rnd.getrandbits(250) for _ in range(16)]
-    for label, vals in (("all_equal", [0x1234567890ABCDEF1234567] * n), ("bits", [rnd.getrandbits(1) for _ in range(n)]),
-                        ("sixteen_values", [vals16[rnd.randrange(16)] for _ in range(n)])):
+    # (round 4: at this size a coarse bin of more than 32 768 records is cut into slices of 8 192 for k_fine_huge_count / _place --
+    # every case below has such bins: one per window, one in window 0, the carry bucket of window 1, two per window, ...)
+    cases = (("all_equal", [0x1234567890ABCDEF1234567] * n), ("bits", [rnd.getrandbits(1) for _ in range(n)]),
+             ("sixteen_values", [vals16[rnd.randrange(16)] for _ in range(n)]),
+             ("zero_or_minus_one", [(ctx.r - 1) * rnd.getrandbits(1) for _ in range(n)]),          # a_R = a_L - 1 of a bit vector (positive_no.rs:18-24)
+             ("8_bit", [rnd.getrandbits(8) for _ in range(n)]), ("16_bit", [rnd.getrandbits(16) for _ in range(n)]),
+             ("mostly_one_value", [vals16[0] if rnd.randrange(10) else rnd.getrandbits(250) for _ in range(n)]))
+    for label, vals in cases:
         ss = b"".join(v.to_bytes(32, "little") for v in vals)
         sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
         t0 = time.time()
         got = pts.multi_scalar_mul_var_time(sv)
         dt = time.time() - t0
-        assert got == O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen), label
+        want = O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen)
+        assert got == want, label
         assert dt < 2.0, (label, dt)      # no pathological serialisation
+        if label in ("bits", "8_bit"):    # ... and ragged: the last slice of a bin is short, the last tile of the scalars too
+            m = n - 12345
+            assert pts.msm_range(0, sv, 0, m) == O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks[:32 * m], ss[:32 * m], m), gen), label
+    # the merged-window pipeline over a table has the same bins per scalar set
+    pts.precompute(16)
+    for label, vals in cases[1:4]:
+        ss = b"".join(v.to_bytes(32, "little") for v in vals)
+        sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+        assert pts.multi_scalar_mul_var_time(sv) == O.g1_mul(ctx.curve, O.fr_inner(ctx.curve, ks, ss, n), gen), ("table", label)
     pts.free()
 
 

@@ -99,6 +99,21 @@ def test_r1cs_golden_fixture(bp, golden, name):
             with pytest.raises(bp.VerificationError):
                 bp.r1cs_verify(ctx, start_transcript(bp, ctx, a["label"], a["V"]), plan, Gv, Hv, a["g"], a["h"], O.generator(ctx.curve) + Vb[pb:], n,
                                a["proof"], a["r"])
+        # the same verdicts with the [G | H] terms over the generators' window tables (verifier.rs:431-451; the knob brings the
+        # size limit down to the fixtures'), the proof's and the statement's points as the small MSM beside them
+        if pn >= 2:
+            ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 2)
+            Gv.precompute(8)
+            Hv.precompute(8)
+            bp.r1cs_verify(ctx, start_transcript(bp, ctx, a["label"], a["V"]), plan, Gv, Hv, a["g"], a["h"], Vb, n, a["proof"], a["r"])
+            assert ctx.verify_table_info()[0] == pn
+            with pytest.raises(bp.VerificationError):
+                bp.r1cs_verify(ctx, start_transcript(bp, ctx, a["label"], a["V"]), plan, Gv, Hv, a["g"], a["h"], Vb, n, bytes(bad), a["r"])
+            if m:
+                with pytest.raises(bp.VerificationError):
+                    bp.r1cs_verify(ctx, start_transcript(bp, ctx, a["label"], a["V"]), plan, Gv, Hv, a["g"], a["h"], O.generator(ctx.curve) + Vb[pb:], n,
+                                   a["proof"], a["r"])
+            ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 0)
         plan.free()
     ctx.close()
 
@@ -235,8 +250,11 @@ def test_cfg3_full_chain_vs_oracle(bp):
         proof_t = bp.r1cs_prove(ctx, start_transcript(bp, ctx, b"cfg3", V), plan, Gv, Hv, g, h, fe(aL, n), fe(aR, n), fe(aO, n), fe(vb, m), fe(sL, n),
                                 fe(sR, n), bl)
         assert proof_t == want
-        # 3. the library's verifier accepts it, and both reject a changed proof / statement
+        # 3. the library's verifier accepts it, and both reject a changed proof / statement.  G and H carry tables here: with the knob on
+        # their terms run over them, the 3 072 commitments and the proof's points as a second MSM beside; then the plain path
+        ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 4096)
         bp.r1cs_verify(ctx, start_transcript(bp, ctx, b"cfg3", V), plan, Gv, Hv, g, h, Vb, n, proof, rnd)
+        assert ctx.verify_table_info()[0] == n
         pb = ctx.point_bytes
         for off in (11 * pb + 5, 7 * pb + 1, len(proof) - 40):            # t_x, T_3, a
             bad = bytearray(proof)
@@ -247,6 +265,10 @@ def test_cfg3_full_chain_vs_oracle(bp):
         bad[11 * pb + 5] ^= 4
         assert O.r1cs_verify(cid, O.r1cs_start_transcript(cid, b"cfg3", V), T, Vb, bytes(bad), g, h, Gb, Hb, n, rnd) == 3
         V2 = [V[1], V[0]] + V[2:]
+        with pytest.raises(bp.VerificationError):
+            bp.r1cs_verify(ctx, start_transcript(bp, ctx, b"cfg3", V2), plan, Gv, Hv, g, h, b"".join(V2), n, proof, rnd)
+        ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 0)
+        bp.r1cs_verify(ctx, start_transcript(bp, ctx, b"cfg3", V), plan, Gv, Hv, g, h, Vb, n, proof, rnd)
         with pytest.raises(bp.VerificationError):
             bp.r1cs_verify(ctx, start_transcript(bp, ctx, b"cfg3", V2), plan, Gv, Hv, g, h, b"".join(V2), n, proof, rnd)
         plan.free()
@@ -279,13 +301,20 @@ def test_ipp_2p16_vs_oracle(bp):
             Hv.precompute(c)
             pt = bp.IPP.create_ipp(ctx, bp.Transcript(b"ipp 2^16"), Q, fe(Gf), fe(Hf), Gv, Hv, fe(a), fe(b))
             assert (pt.L, pt.R, pt.a, pt.b) == want, c
-        Gv.drop_table()
-        Hv.drop_table()
-        # P = <a, Gf o G> + <b, Hf o H> + <a, b> Q (src/ipp.rs:353-372) and both verifiers
+        # P = <a, Gf o G> + <b, Hf o H> + <a, b> Q (src/ipp.rs:353-372) and both verifiers (the library's over the tables, then without)
         sc = fe(a).hadamard_product(fe(Gf)).to_bytes() + fe(b).hadamard_product(fe(Hf)).to_bytes() + fe(a).inner_product(fe(b))
         P = bp.G1Vector.from_bytes(ctx, pts, 2 * n + 1).multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, sc, 2 * n + 1))
         assert O.ipp_verify(cid, O.Transcript(b"ipp 2^16"), n, Gf, Hf, P, Q, Gb, Hb, proof.a, proof.b, proof.L, proof.R, proof.lg_n) == 0
+        ctx.set_tuning(bp.TUNE_VERIFY_TABLES, 2)
         bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"ipp 2^16"), fe(Gf), fe(Hf), P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+        assert ctx.verify_table_info()[0] == n
+        with pytest.raises(bp.VerificationError):
+            bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"ipp 2^16"), fe(Gf), fe(Hf), P, Q, Gv, Hv, proof.b, proof.a, proof.L, proof.R)
+        Gv.drop_table()
+        Hv.drop_table()
+        ctx.drop_verify_table()
+        bp.IPP.verify_ipp(ctx, n, bp.Transcript(b"ipp 2^16"), fe(Gf), fe(Hf), P, Q, Gv, Hv, proof.a, proof.b, proof.L, proof.R)
+        assert ctx.verify_table_info() == (0, 0)
         ctx.close()
     finally:
         O.set_threads(1)
