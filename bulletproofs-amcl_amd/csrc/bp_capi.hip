@@ -376,10 +376,10 @@ struct Impl {
         uint32_t* nonempty = win_done + kMaxWindows;                    // per window: buckets that hold anything (k_fine_place -> task_len)
         uint32_t* nslices = nonempty + kMaxWindows;
         // Huge coarse bins (structured scalars: bit vectors, a few distinct values, small values) get a block per 8192 records instead of
-        // one block for the bin -- from 2^22 records on, where one block streaming half of them was the whole sort.
+        // one block for the bin -- from 2^20 records on (2^16 scalars x 16 windows): below, a bin cannot hold more than a block streams in
+        // ~0.1 ms, and the two extra launches (~5 us when there is nothing to do) would be felt.
         const size_t nrecs = (size_t)W * n;
-        static const size_t huge_from = getenv("BP_HUGE_FROM") ? (size_t)atol(getenv("BP_HUGE_FROM")) : (size_t)1 << 22;
-        const size_t max_slices = nrecs >= huge_from ? nrecs / kHugeSlice + nrecs / kHugeMin + 2 : 0;
+        const size_t max_slices = nrecs >= ((size_t)1 << 20) ? nrecs / kHugeSlice + nrecs / kHugeMin + 2 : 0;
         if (max_slices && (rc = ctx->huge.reserve(ctx, max_slices * (sizeof(HugeSlice) + kBlock * 4)))) return rc;
         HugeSlice* slices = max_slices ? (HugeSlice*)ctx->huge.p : nullptr;
         uint32_t* slice_hist = max_slices ? (uint32_t*)((uint8_t*)ctx->huge.p + max_slices * sizeof(HugeSlice)) : nullptr;
@@ -390,20 +390,28 @@ struct Impl {
         uint32_t* heavy = (uint32_t*)ctx->heavy.p;
         uint2* chunks = (uint2*)ctx->heavy_chunks.p;
 
+        // scalar negation (k_digits_bin): one bit per scalar and set, one flag word per tile and set
+        const size_t nw64 = (n + 63) / 64;
+        if ((rc = ctx->negbits.reserve(ctx, (size_t)tab.nsets * (nw64 * 8 + (size_t)ntiles * 4)))) return rc;
+        uint64_t* negbits = (uint64_t*)ctx->negbits.p;
+        uint32_t* tile_neg = (uint32_t*)(negbits + (size_t)tab.nsets * nw64);
+        ScalarWords rmod, rneg;
+        for (int k = 0; k < 8; k++) rmod.w[k] = rneg.w[k] = C::Fr::Words::MODW[k];
+        for (int k = 4; k < 8; k++) { const bool more = rneg.w[k] == 0; rneg.w[k]--; if (!more) break; }             // r - 2^128
         if (tm) HIPCHK(hipEventRecord(ctx->ev[0], st));
         HIPCHK(hipMemsetAsync(ctx->meta.p, 0, kMetaWords * 4, st));
-        hipLaunchKernelGGL(k_digits_bin, dim3(ntiles), dim3(kBlock), 0, st, sc, sc2, n, tab, ntiles, tile, code, tile_hist);
+        hipLaunchKernelGGL(k_digits_bin, dim3(ntiles), dim3(kBlock), 0, st, sc, sc2, n, tab, ntiles, tile, code, tile_hist, rmod, rneg, negbits, nw64, tile_neg);
         BP_TRACE_SYNC(ctx, "k_digits_bin");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, hsum);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)hist_blocks), dim3(kBlock), 0, st, tile_hist, nhist, hsum, tile_hist, (uint32_t*)nullptr);
         BP_TRACE_SYNC(ctx, "scan tile_hist");
         if (tm) HIPCHK(hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, W), dim3(kBlock), 0, st, code, n, tab, ntiles, tile_hist, tmp_rec, 0, tile);
+        hipLaunchKernelGGL(k_coarse_scatter, dim3(ntiles, W), dim3(kBlock), 0, st, code, n, tab, ntiles, tile_hist, tmp_rec, 0, tile, negbits, nw64, tile_neg);
         BP_TRACE_SYNC(ctx, "k_coarse_scatter");
         hipLaunchKernelGGL(k_fine_place, dim3(128, WR), dim3(kBlock), 0, st, tmp_rec, tabR, ncols, tile_hist, hsum + hist_blocks, count, cursor, idx, 0, nonempty, slices, nslices);
         if (max_slices) {
-            const unsigned sg = (unsigned)(max_slices < 2048 ? max_slices : 2048);
+            const unsigned sg = (unsigned)(max_slices < 1024 ? max_slices : 1024);
             hipLaunchKernelGGL(k_fine_huge_count, dim3(sg), dim3(kBlock), 0, st, tmp_rec, tabR, slices, nslices, slice_hist);
             hipLaunchKernelGGL(k_fine_huge_place, dim3(sg), dim3(kBlock), 0, st, tmp_rec, tabR, slices, nslices, slice_hist, count, cursor, idx, nonempty);
         }
@@ -1093,7 +1101,7 @@ int bp_ctx_destroy(bp_ctx* ctx) {
     ctx->fixed_base_table.release();
     if (ctx->gh_table) { bp_internal_table_free(ctx->gh_table); ctx->gh_table = nullptr; }
     for (DevBuf* b : {&ctx->count, &ctx->cursor, &ctx->block_sums, &ctx->idx, &ctx->code, &ctx->tile_hist, &ctx->tmp_idx, &ctx->ntasks, &ctx->task_off, &ctx->order, &ctx->t_start,
-                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags, &ctx->huge}) b->release();
+                      &ctx->t_len, &ctx->tsum, &ctx->heavy, &ctx->heavy_chunks, &ctx->meta, &ctx->partial, &ctx->window_sum, &ctx->scratch, &ctx->flags, &ctx->huge, &ctx->negbits}) b->release();
     if (ctx->pool) { ctx->pool->trim(); ctx->pool->release(); }     // cached blocks go back to the driver now; live handles keep the (empty) pool alive
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->stage) (void)hipHostFree(ctx->stage);

@@ -145,7 +145,7 @@ struct bp_ctx {
     // MSM workspace
     DevBuf fixed_base_table;            // d * 2^(4j) * G, built on first use (bp_g1vec_fixed_base_mul)
     bool fixed_base_ready = false;
-    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch, huge;
+    DevBuf count, cursor, block_sums, idx, code, tile_hist, tmp_idx, ntasks, task_off, order, t_start, t_len, tsum, heavy, heavy_chunks, meta, partial, window_sum, scratch, huge, negbits;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     void* stage = nullptr;              // page-locked ring for small host -> device copies of LIBRARY-made data that must not wait for the

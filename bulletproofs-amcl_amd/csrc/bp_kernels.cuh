@@ -106,6 +106,26 @@ __device__ __forceinline__ void shr256(uint64_t (&q)[4], int k) {
     }
 }
 
+// a > b, and a = m - a, on canonical 8-word values (the scalar negation of k_digits_bin)
+__device__ __forceinline__ bool gt256(const ScalarWords& a, const ScalarWords& b) {
+    bool gt = false, eq = true;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        gt = gt || (eq && a.w[i] > b.w[i]);
+        eq = eq && a.w[i] == b.w[i];
+    }
+    return gt;
+}
+__device__ __forceinline__ void rsub256(ScalarWords& a, const ScalarWords& m) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)m.w[i] - a.w[i] - borrow;
+        a.w[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+}
+
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* lds, uint32_t& block_total);
 
 // Sorting point indices by (window, bucket) -- a two-level binning sort, all atomics in LDS:
@@ -118,9 +138,18 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t
 //                  the 4-byte stores combine in L2 instead of costing a 64-byte write-back each.
 // (The first version -- global-atomic histogram + global random scatter -- took 0.63 + 1.48 ms at n = 2^20 with 1.0 GB
 // of WRITE_SIZE for 64 MB of useful output: profiles/r01_bench_n1_pmc_hbm.json.)
+// Scalar negation (round 4): a scalar k > r - 2^128 ("a small negative number": rneg = r - 2^128) is recoded as r - k and its point enters
+// its buckets NEGATED (negbits: one bit per scalar and set, applied to the sign of the entries by k_coarse_scatter; tile_neg: whether a
+// tile has any, so that tiles without pay one flag load).  The a_R = a_L - 1 of a bit decomposition (/root/reference
+// src/r1cs/gadgets/helper_constraints/positive_no.rs:18-24) is 0 or r - 1: one non-zero digit instead of one in every window.
+// (Negating every k > r / 2 was measured first: uniform scalars then leave half of the TOP window's buckets empty and fill the others twice
+// as high -- reduce 0.42 -> 0.57 ms at 2^20.  A uniform scalar meets the 2^-127 rule never.)
 static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords* __restrict__ scalars, const ScalarWords* __restrict__ scalars2, size_t n,
-                                                             WinTab tab, uint32_t ntiles, uint32_t tile, uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist) {
+                                                             WinTab tab, uint32_t ntiles, uint32_t tile, uint16_t* __restrict__ code, uint32_t* __restrict__ tile_hist,
+                                                             ScalarWords rmod, ScalarWords rneg, uint64_t* __restrict__ negbits, size_t nw64, uint32_t* __restrict__ tile_neg) {
     __shared__ uint32_t lh[kMaxBinRows];
+    __shared__ uint32_t s_anyneg;
+    if (threadIdx.x == 0) s_anyneg = 0;                   // (the barrier after the histogram's zeroing orders it)
     const bool mg = tab.merged != 0;
     const uint32_t mbins = 1u << (tab.cw[0] - 1 - tab.fbits[0]);          // merged: coarse bins of a set (same for every window)
     const uint32_t rows = mg ? (uint32_t)tab.W * mbins : tab.hoff[tab.W];  // LDS rows: one histogram per WINDOW in both modes
@@ -129,6 +158,7 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
     size_t base = (size_t)blockIdx.x * tile;
     const int wps = tab.W / tab.nsets;   // windows per scalar set (same geometry for every set)
     const uint32_t per = tile / kBlock;   // scalars per lane (tile is a multiple of kBlock)
+    uint32_t anyneg = 0;                  // bit `set`: this lane saw a negated scalar of that set
 #pragma unroll 1
     for (uint32_t e0 = 0; e0 < per; e0 += kDigitBatch) {
       // kDigitBatch scalars per lane are loaded before the first is recoded (the loop was paced by one 32-byte load per iteration)
@@ -142,7 +172,14 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
 #pragma unroll
         for (int u = 0; u < kDigitBatch; u++) {
             size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
-            if (e0 + u < per && i < n) {
+            const bool valid = e0 + u < per && i < n;
+            if (negbits) {                                   // (a wave holds 64 consecutive scalars, the first a multiple of 64)
+                bool neg = false;
+                if (valid) { neg = gt256(sw[u], rneg); if (neg) { rsub256(sw[u], rmod); anyneg |= 1u << set; } }
+                const uint64_t m = __ballot(neg);
+                if ((threadIdx.x & 63) == 0 && valid) negbits[(size_t)set * nw64 + (i >> 6)] = m;
+            }
+            if (valid) {
                 uint64_t q[4];
                 add256(q, sw[u], tab.bias);
                 if (const int off0 = tab.off[set * wps]) shr256(q, off0);      // a window SUBSET (sharded callers): its first window starts above bit 0
@@ -161,7 +198,9 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
         }
       }
     }
+    if (anyneg) atomicOr(&s_anyneg, anyneg);
     __syncthreads();
+    if (tile_neg && threadIdx.x < (uint32_t)tab.nsets) tile_neg[(size_t)threadIdx.x * ntiles + blockIdx.x] = (s_anyneg >> threadIdx.x) & 1u;
     if (!mg) {
         for (uint32_t k = threadIdx.x; k < rows; k += kBlock) tile_hist[(size_t)k * ntiles + blockIdx.x] = lh[k];
     } else {
@@ -177,7 +216,8 @@ static __global__ void __launch_bounds__(kBlock) k_digits_bin(const ScalarWords*
 // per element: the kernel is bound by the address processing of its scattered stores (64 lanes, 64 different runs), and one
 // store instruction per element instead of two (2-byte code + 4-byte index) matters more than the 2 extra bytes.
 static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t* __restrict__ code, size_t n, WinTab tab, uint32_t ntiles,
-                                                                 const uint32_t* __restrict__ tile_off, uint2* __restrict__ tmp_rec, int w0, uint32_t tile) {
+                                                                 const uint32_t* __restrict__ tile_off, uint2* __restrict__ tmp_rec, int w0, uint32_t tile,
+                                                                 const uint64_t* __restrict__ negbits, size_t nw64, const uint32_t* __restrict__ tile_neg) {
     __shared__ uint32_t lcur[128];
     const int w = w0 + (int)blockIdx.y;
     const int c = tab.cw[w], fb = tab.fbits[w];
@@ -191,16 +231,22 @@ static __global__ void __launch_bounds__(kBlock) k_coarse_scatter(const uint16_t
     const uint32_t half1 = (1u << (c - 1)) - 1;
     const uint32_t per = tile / kBlock;
     const uint32_t row0 = mg ? (uint32_t)(w % tab.W1) * (uint32_t)n : 0u;      // merged: the entry names a row of the window-multiples table
+    const int set = w / (tab.W / tab.nsets);                                    // this window's scalar set; its negation bits only if the tile has any
+    const uint64_t* nbits = negbits && tile_neg[(size_t)set * ntiles + blockIdx.x] ? negbits + (size_t)set * nw64 : nullptr;
     for (uint32_t e0 = 0; e0 < per; e0 += kFineBatch) {      // kFineBatch codes per lane in flight
         uint32_t raw[kFineBatch];
+        uint64_t nb[kFineBatch];
 #pragma unroll
         for (int u = 0; u < kFineBatch; u++) {
             size_t i = base + (size_t)(e0 + u) * kBlock + threadIdx.x;
-            raw[u] = (e0 + u < per && i < n) ? code[(size_t)w * n + i] : half1;
+            const bool valid = e0 + u < per && i < n;
+            raw[u] = valid ? code[(size_t)w * n + i] : half1;
+            nb[u] = valid && nbits ? nbits[i >> 6] : 0;
         }
 #pragma unroll
         for (int u = 0; u < kFineBatch; u++) {
             int d = (int)raw[u] - (int)half1;
+            if ((nb[u] >> (threadIdx.x & 63)) & 1) d = -d;               // the scalar was recoded as r - k: its point enters negated
             if (d != 0) {
                 uint32_t pos = atomicAdd(&lcur[((uint32_t)(d < 0 ? -d : d) - 1) >> fb], 1u);
                 tmp_rec[pos] = make_uint2(row0 + (uint32_t)(base + (size_t)(e0 + u) * kBlock + threadIdx.x), (uint32_t)d);     // (row, signed digit)

@@ -23,7 +23,11 @@ def small(bits):
 def few(k):
     vals = np.frombuffer(rand_scalars(ctx, k, 9), dtype=np.uint8).reshape(k, 32)
     return vals[rng.integers(0, k, size=n)].tobytes()
-kinds = {"uniform": rand_scalars(ctx, n, 2), "bits": small(1), "8-bit": small(8), "16-bit": small(16), "20-bit": small(20), "32-bit": small(32), "2 values": few(2), "16 values": few(16),
+def zero_or_minus_one():      # a_R = a_L - 1 of a bit decomposition (positive_no.rs:18-24): 0 or r - 1
+    a = np.zeros((n, 32), dtype=np.uint8)
+    a[rng.integers(0, 2, size=n) == 1] = np.frombuffer((ctx.r - 1).to_bytes(32, "little"), dtype=np.uint8)
+    return a.tobytes()
+kinds = {"uniform": rand_scalars(ctx, n, 2), "bits": small(1), "0 or r-1": zero_or_minus_one(), "8-bit": small(8), "16-bit": small(16), "20-bit": small(20), "32-bit": small(32), "2 values": few(2), "16 values": few(16),
          "256 values": few(256), "4096 values": few(4096)}
 only = [k.strip() for k in os.environ.get("TS_KINDS", "").split(",") if k.strip()]      # e.g. TS_KINDS="bits,256 values"
 for name, sb in kinds.items():

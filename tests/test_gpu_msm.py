@@ -165,10 +165,22 @@ def test_msm_skewed_scalars(bp, ctxs, name):
         ("bits", [rnd.getrandbits(1) for _ in range(n)]),
         ("all_equal", [0x1234567] * n),
         ("zeros_1pct", [0 if rnd.random() < 0.01 else rnd.getrandbits(250) for _ in range(n)]),
+        # small negative scalars are recoded as r - k with the point negated (k_digits_bin, round 4): a_R = a_L - 1 of a bit vector, small
+        # negative weights, and the rule's boundary r - 2^128 (the last scalar NOT negated) with its neighbours, among ordinary scalars
+        ("zero_or_minus_one", [(ctx.r - 1) * rnd.getrandbits(1) for _ in range(n)]),
+        ("small_negatives", [(ctx.r - rnd.getrandbits(rnd.choice((1, 8, 64, 127, 128)))) % ctx.r if rnd.getrandbits(1) else rnd.getrandbits(250) for _ in range(n)]),
+        ("negation_boundary", [ctx.r - (1 << 128) + rnd.choice((-2, -1, 0, 1, 2)) if rnd.getrandbits(2) else rnd.getrandbits(250) for _ in range(n)]),
     ):
         ss = b"".join(v.to_bytes(32, "little") for v in vals)
-        got = pts.multi_scalar_mul_var_time(bp.FieldElementVector.from_bytes(ctx, ss, n))
-        assert got == O.msm(ctx.curve, host, ss, n, algo=O.PIPPENGER, nthreads=8), label
+        sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+        got = pts.multi_scalar_mul_var_time(sv)
+        want = O.msm(ctx.curve, host, ss, n, algo=O.PIPPENGER, nthreads=8)
+        assert got == want, label
+        if label in ("small_negatives", "negation_boundary"):          # ... as the second scalar set of a paired MSM, and ragged (a tile of 64 x k + 17 scalars)
+            other = bp.FieldElementVector.from_bytes(ctx, O.random_scalars(ctx.curve, 32, n), n)
+            assert pts.multi_scalar_mul_pair(other, sv)[1] == want, label
+            m = n - 2031
+            assert pts.msm_range(0, sv, 0, m) == O.msm(ctx.curve, host[:m * ctx.point_bytes], ss[:32 * m], m, algo=O.PIPPENGER, nthreads=8), label
 
 
 @pytest.mark.parametrize("name,lg", [("bls12_381", 20), ("bn254", 20), ("bls12_381", 22)])
