@@ -167,6 +167,46 @@ def test_unequal_shards_need_a_common_width(bp, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["bls12_381", "bn254"])
+def test_index_x_window_groups_with_structured_scalars(bp, name):
+    """The 2-D split (index range x window group, bp_msm_g1_windows_subset + bp_msm_g1_finish_blocks) over scalars that the recoding treats
+    specially: bit vectors, their complements 0 / r - 1 and other small negatives (recoded as r - k with the point negated -- every
+    window group of a rank must negate the same scalars), values at the rule's boundary, all mixed with uniform ones.  Every split of 4
+    'ranks' gives the single MSM's and the oracle's point."""
+    import random
+    import torch
+    from bulletproofs_amcl_amd import sharding
+    cid = bp.CURVE_IDS[name]
+    ctx = bp.Context(cid, 0)
+    n, world = 40000, 4
+    rnd = random.Random(99)
+    ks = O.random_scalars(cid, 5101, n)
+    pts = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, ks, n))
+    kinds = (lambda: rnd.getrandbits(1), lambda: (ctx.r - 1) * rnd.getrandbits(1), lambda: ctx.r - 1 - rnd.getrandbits(rnd.choice((3, 60, 127))),
+             lambda: ctx.r - (1 << 128) + rnd.choice((-1, 0, 1)), lambda: rnd.randrange(ctx.r))
+    ss = b"".join(rnd.choice(kinds)().to_bytes(32, "little") for _ in range(n))
+    sv = bp.FieldElementVector.from_bytes(ctx, ss, n)
+    want = O.g1_mul(cid, O.fr_inner(cid, ks, ss, n), O.generator(cid))
+    assert pts.multi_scalar_mul_var_time(sv) == want
+    rb = bp.msm_record_bytes(cid)
+    c, cw, _, _ = bp.msm_geometry(cid, n // world)
+    W = len(cw)
+    ctx.set_window_bits(c)
+    for wg in (1, 2, 4):
+        if W % wg:
+            continue
+        n_set = n // (world // wg)
+        stride = max(bp.msm_window_records_subset(ctx, n_set, g * (W // wg), W // wg) for g in range(wg))
+        blocks = torch.zeros(world * stride * rb, dtype=torch.uint8, device="cuda:0")
+        for r in range(world):
+            lo, hi, w0, wn = sharding.shard_2d(n, world, r, W, wg)
+            bp.msm_windows_subset(ctx, pts, lo, sv, lo, hi - lo, w0, wn, stride, blocks.data_ptr() + r * stride * rb)
+        assert bp.msm_finish_blocks(ctx, blocks.data_ptr(), world, stride, n_set) == want, wg
+        assert bp.msm_finish_blocks_host(cid, bytes(blocks.cpu().tolist()), world, stride, n_set, c) == want, wg
+    ctx.set_window_bits(0)
+    ctx.close()
+
+
 def test_cfg4_split_of_2p22_over_8_shards(bp):
     """BASELINE config 4 on one GPU: 2^22 points as 8 contiguous shards of 2^19 (one context each, as 8 ranks / devices would
     hold them) through bp_msm_g1_multi, and through bp_msm_g1_windows + bp_msm_g1_finish(sets = 8); both equal the single
