@@ -132,6 +132,7 @@ SYMBOLS = {
     "bp_fr_inner_product": (_I, [_P, _P, _SZ, _P, _SZ, _SZ, _U8P]),
     "bp_fr_hadamard": (_I, [_P, _P, _P, _PP]),
     "bp_fr_scaled_by": (_I, [_P, _P, _U8P, _PP]),
+    "bp_fr_glv_split": (_I, [_P, _P, _PP]),
     "bp_fr_vandermonde": (_I, [_P, _U8P, _SZ, _PP]),
     "bp_fr_inverse": (_I, [_I, _U8P, _U8P]),
     "bp_vecpoly3_special_inner_product": (_I, [_P, _PP, _PP, _U8P]),
@@ -629,6 +630,13 @@ def _fr_hadamard(self, other):
     return FieldElementVector(self.ctx, h)
 
 
+def _fr_glv_split(self):
+    """the two 128-bit halves of every scalar under the curve's GLV endomorphism (bp_fr_glv_split): 16 bytes s1 | 16 bytes s2 per element"""
+    h = ctypes.c_void_p()
+    _check(lib().bp_fr_glv_split(self.ctx.h, self.h, ctypes.byref(h)), "bp_fr_glv_split")
+    return FieldElementVector(self.ctx, h)
+
+
 def _fr_scaled_by(self, s_le32):
     """FieldElementVector::scaled_by"""
     h = ctypes.c_void_p()
@@ -647,6 +655,7 @@ FieldElementVector.inner_product = _fr_inner_product
 FieldElementVector.copy_from = _fr_copy_from
 FieldElementVector.hadamard_product = _fr_hadamard
 FieldElementVector.scaled_by = _fr_scaled_by
+FieldElementVector.glv_split = _fr_glv_split
 FieldElementVector.new_vandermonde_vector = classmethod(_fr_vandermonde)
 
 

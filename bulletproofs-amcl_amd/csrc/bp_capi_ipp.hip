@@ -35,7 +35,7 @@ struct bp_ipp_state {
     bp_g1table* table;       // window multiples of [G | H | Q] when G and H carry tables (bp_g1vec_precompute): every round's MSM is merged-window
     // generator compaction (bp_compact.cuh): once the live length has shrunk to compact_at the folded generators are materialised and
     // the remaining rounds run as single-launch rounds over THEIR digit multiples (n0, Pall, cG, cH, table then describe the compacted set)
-    bool glv;                // the compaction (and the rounds after it) work on GLV-split scalars (BLS12-381, no compaction tables, BP_TUNE_GLV)
+    bool glv;                // the compaction (and the rounds after it) work on GLV-split scalars (no compaction tables, BP_TUNE_GLV)
     size_t compact_at;       // 0: this proof never compacts
     bool compacted;
     const bp_g1table *ctG, *ctH;   // compaction tables of G and H (bp_g1vec_precompute) when both have one: nothing to build, Horner chain of 60 doublings
@@ -206,6 +206,27 @@ struct Ipp {
         if (rc) { ctx->pool->put(d, cap); return rc; }
         ctx->pool->put(t->d, t->cap);            // recycled in stream order: the conversion above is queued before any later user
         t->d = d; t->cap = cap; t->affine = true;
+        return BP_OK;
+    }
+
+    // The 16 affine digit multiples of [G | H | Q] for k_small_msm_glv: a proof of 1024 .. 4096 generators (no compaction) runs ALL its rounds
+    // over scalars split in two halves (half the windows per launch, half the doublings in every host tail) when the curve has the split.
+    static int glv_round_table(bp_ipp_state* st) {
+        bp_ctx* ctx = st->ctx;
+        const size_t m = 2 * st->n0 + 1, rows = kGlvRows;
+        PoolBlock b_mx;
+        if (!b_mx.alloc(ctx, rows * m * sizeof(XyzzPacked<C>))) return BP_ERR_DEVICE;
+        hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const AffPacked<C>*)st->Pall, (uint32_t)m,
+                           (XyzzPacked<C>*)b_mx.p, (uint32_t)rows);
+        HIPCHK(hipGetLastError());
+        bp_g1table* t = new (std::nothrow) bp_g1table();
+        if (!t) return BP_ERR_DEVICE;
+        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = kGlvBits; t->W = (int)rows; t->digits = true; t->affine = true; t->glv = true;
+        t->d = ctx->pool->get(rows * m * kPt, &t->cap);
+        if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+        int rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rows * m, (AffPacked<C>*)t->d, ctx->stream, nullptr);
+        if (rc) { bp_internal_table_free(t); return rc; }
+        st->table = t;
         return BP_OK;
     }
 
@@ -380,7 +401,7 @@ struct Ipp {
             if (gx > 1024) gx = 1024;
             if (gx < g) gx = g;
             bool split = false;
-            if constexpr (C::HAS_GLV) split = st->compacted && st->table && st->table->glv;
+            if constexpr (C::HAS_GLV) split = st->table && st->table->glv;
             if (split) {
                 if constexpr (C::HAS_GLV) {
                     hipLaunchKernelGGL((k_ipp_round_prep<C, true>), dim3(gx, 3), dim3(kBlock), 0, ctx->stream, a, b, (const ScalarWords*)st->cG, (const ScalarWords*)st->cH, st->n0,
@@ -1157,6 +1178,23 @@ int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_fr
     });
 }
 
+// out[i] = the two halves of a[i] under the curve's endomorphism, as the prover's kernels use them (bp_compact.cuh: glv_decompose):
+// 16 bytes s1 then 16 bytes s2, little-endian, a[i] = s1 + s2 LAMBDA mod r.  BLS12-381: both halves plain numbers < 2^128; BN254: s2 mod
+// 2^128, negative when >= 2^66 (bp_curve.cuh).  Same length and byte size as a scalar vector, so it travels as one.
+int bp_fr_glv_split(bp_ctx* ctx, const bp_frvec* a, bp_frvec** out) {
+    return bp_guard([&]() -> int {
+    if (!ctx || !a || !out) return BP_ERR_ARG;
+    int rc = alloc_frvec(ctx, a->n, out); if (rc) return rc;
+    if (a->n == 0) return BP_OK;
+    if (ctx->curve == BP_CURVE_BLS12_381)
+        hipLaunchKernelGGL(k_glv_decompose<Bls381>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, (const ScalarWords*)nullptr, a->n, (ScalarWords*)(*out)->d, (ScalarWords*)nullptr);
+    else
+        hipLaunchKernelGGL(k_glv_decompose<Bn254>, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, (const ScalarWords*)a->d, (const ScalarWords*)nullptr, a->n, (ScalarWords*)(*out)->d, (ScalarWords*)nullptr);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+    });
+}
+
 int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** out) {
     return bp_guard([&]() -> int {
     if (!ctx || !e_le32 || !out) return BP_ERR_ARG;
@@ -1420,10 +1458,17 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
         // ... but every round is a small MSM over the SAME 2n + 1 points: their digit multiples, once (one ~0.1 ms launch for lg n rounds
         // that each lose the per-lane doubling chain; same-box A/B: n = 64 2.24-2.51 -> 2.04-2.07 ms per proof, n = 128 2.94-3.26 ->
         // 2.38-2.42, n = 16 1.35-1.60 -> 1.28-1.30; at n = 4 the launch costs more than two rounds save: 0.66 -> 0.72)
-        rc = bp_internal_digit_table_build(ctx, st->Pall, 2 * n + 1, &st->table);
-        // ... and from ~4 terms per lane on as AFFINE rows (one batch inversion, ~60 us with its host round trip): the lanes' serial
-        // chains are then mixed additions (8M + 2S instead of 12M + 2S per term)
-        if (!rc && n >= 1024) rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::digit_table_to_affine(ctx, st->table) : Ipp<Bn254>::digit_table_to_affine(ctx, st->table);
+        // ... from ~4 terms per lane on as AFFINE rows (one batch inversion, ~60 us with its host round trip): the lanes' serial chains are
+        // then mixed additions (8M + 2S instead of 12M + 2S per term) -- and, with the scalars split by the curve's endomorphism
+        // (BP_TUNE_GLV), 16 multiples for 26 windows of 5 bits per half instead of 8 for 64 windows of 4 bits: k_small_msm_glv
+        // (from 1024 generators on: below, the 16-row table and its inversion cost what the shorter rounds save -- n = 64 1.43-1.53 ms
+        // either way, BN254 n = 512 1.74-1.93 without against 1.93-1.97 with, same box)
+        if (n >= 1024 && ctx->tuning.glv && (ctx->curve == BP_CURVE_BLS12_381 ? Bls381::HAS_GLV : Bn254::HAS_GLV)) {
+            rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::glv_round_table(st) : Ipp<Bn254>::glv_round_table(st);
+        } else {
+            rc = bp_internal_digit_table_build(ctx, st->Pall, 2 * n + 1, &st->table);
+            if (!rc && n >= 1024) rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::digit_table_to_affine(ctx, st->table) : Ipp<Bn254>::digit_table_to_affine(ctx, st->table);
+        }
         if (rc) { bp_ipp_state_free(st); return rc; }
     }
     *out = st;

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(4 * kHornerQuads) k_compact_horner(const XyzzP
     }
 }
 
-// ---------------------------------------------------------------------------------------------- GLV: half-length scalars (BLS12-381)
+// ---------------------------------------------------------------------------------------------- GLV: half-length scalars (BLS12-381, BN254)
 // s P = s1 P + s2 phi(P) with s1, s2 < 2^128 (bp_curve.cuh: GLV_LAMBDA): everything that is a strictly serial chain over the bits of a
 // scalar halves -- the Horner chain of the compaction (252 -> 125 doublings) and the host tail of every round that follows (records
 // at bit positions < 130 instead of < 256) -- at the same number of additions: twice the terms, half the windows.
@@ -342,10 +342,53 @@ __device__ __forceinline__ void mac192(uint64_t (&acc)[3], uint64_t a, uint64_t 
 
 // s (canonical, < r) -> s1 = s mod LAMBDA, s2 = floor(s / LAMBDA): Barrett with m = 2^128 + MLO = floor(2^256 / LAMBDA)
 //   q' = floor((s + floor(s MLO / 2^128)) / 2^128) is q or q - 1 (exhaustively at the boundaries + 2e5 random values, Python integers)
+// P (6 words) = s (4 words) * (m1 2^64 + m0)
+__device__ __forceinline__ void mul256x128(const uint64_t (&s)[4], uint64_t m0, uint64_t m1, uint64_t (&P)[6]) {
+    uint64_t acc[3] = {0, 0, 0};
+    mac192(acc, s[0], m0);
+    P[0] = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[0], m1); mac192(acc, s[1], m0);
+    P[1] = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[1], m1); mac192(acc, s[2], m0);
+    P[2] = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[2], m1); mac192(acc, s[3], m0);
+    P[3] = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0;
+    mac192(acc, s[3], m1);
+    P[4] = acc[0]; P[5] = acc[1];
+}
+// (lo, hi) = low 128 bits of (a1 2^64 + a0) * (b1 2^64 + b0)
+__device__ __forceinline__ void mul128lo(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1, uint64_t& lo, uint64_t& hi) {
+    mul64x64(a0, b0, lo, hi);
+    hi += a0 * b1 + a1 * b0;
+}
+
+// The lattice form (BN254, bp_curve.cuh): s1 in [0, 2^128), s2 mod 2^128 (negative when >= 2^66)
+template <class C>
+__device__ __forceinline__ void glv_decompose_lattice(const uint64_t (&s)[4], uint64_t (&s1)[2], uint64_t (&s2)[2]) {
+    uint64_t P[6];
+    mul256x128(s, C::GLV_M1[0], C::GLV_M1[1], P);
+    const uint64_t e1 = (P[4] >> 61) | (P[5] << 3);                                      // >> 317
+    mul256x128(s, C::GLV_M2[0], C::GLV_M2[1], P);
+    const uint64_t e20 = (P[3] >> 62) | (P[4] << 2), e21 = (P[4] >> 62) | (P[5] << 2);   // >> 254
+    uint64_t x0, x1, y0, y1;
+    // s2 = e1 B - e2 A  (mod 2^128)
+    mul128lo(e1, 0, C::GLV_B[0], C::GLV_B[1], x0, x1);
+    mul128lo(e20, e21, C::GLV_A, 0, y0, y1);
+    s2[0] = x0 - y0;
+    s2[1] = x1 - y1 - (uint64_t)(x0 < y0);
+    // s1 = s - e1 A - e2 C  (mod 2^128; the true value is in [0, 2^128))
+    mul128lo(e1, 0, C::GLV_A, 0, x0, x1);
+    mul128lo(e20, e21, C::GLV_C[0], C::GLV_C[1], y0, y1);
+    uint64_t t0 = s[0] - x0, t1 = s[1] - x1 - (uint64_t)(s[0] < x0);
+    s1[0] = t0 - y0;
+    s1[1] = t1 - y1 - (uint64_t)(t0 < y0);
+}
+
 template <class C>
 __device__ __forceinline__ void glv_decompose(const ScalarWords& sw, uint64_t (&s1)[2], uint64_t (&s2)[2]) {
     const uint64_t s[4] = {sw.w[0] | ((uint64_t)sw.w[1] << 32), sw.w[2] | ((uint64_t)sw.w[3] << 32), sw.w[4] | ((uint64_t)sw.w[5] << 32),
                            sw.w[6] | ((uint64_t)sw.w[7] << 32)};
+    if constexpr (C::GLV_SIGNED) { glv_decompose_lattice<C>(s, s1, s2); return; }
     const uint64_t m0 = C::GLV_MLO[0], m1 = C::GLV_MLO[1], l0 = C::GLV_LAMBDA[0], l1 = C::GLV_LAMBDA[1];
     // t = (s * MLO) >> 128: columns of the 4 x 2 word product, three-word running accumulator
     uint64_t acc[3] = {0, 0, 0}, t[4];
@@ -441,6 +484,20 @@ __device__ __forceinline__ void glv_half(const ScalarWords* sc, size_t i, int ki
     hi = h.z | ((uint64_t)h.w << 32);
 }
 
+// ... and its sign: BLS12-381's halves are plain numbers; BN254's second half (kind 1) is a number mod 2^128 that is negative when
+// >= 2^66 (bp_curve.cuh) -- the lane then works with the magnitude and negates its digit.  kind is block-uniform.
+template <class C> __device__ __forceinline__ bool glv_half_signed(const ScalarWords* sc, size_t i, int kind, uint64_t& lo, uint64_t& hi) {
+    glv_half(sc, i, kind, lo, hi);
+    if constexpr (C::GLV_SIGNED) {
+        if (kind == 1 && (hi >> 2) != 0) {
+            lo = 0 - lo;
+            hi = ~hi + (uint64_t)(lo == 0);
+            return true;
+        }
+    }
+    return false;
+}
+
 template <class C> __device__ __forceinline__ Fe<typename C::Fp> glv_beta_mont() { return fe_to_mont<typename C::Fp>(fe_unpack_words<typename C::Fp>(C::BETA)); }
 // phi of a lazy XYZZ point: (BETA X, Y, ZZ, ZZZ) -- phi is a group homomorphism, so it is applied ONCE to a finished partial sum of
 // phi-side terms instead of to every term
@@ -471,8 +528,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_compact_window_sums_glv(const Aff
     uint32_t e = 0;
     auto fetch = [&](uint32_t t, Aff<C>& p, bool& neg) -> bool {
         uint64_t lo, hi;
-        glv_half(sc, j + (size_t)t * nj, (int)kind, lo, hi);
-        const int d = glv_digit<kGlvCBits, kGlvCWin>(lo, hi, (int)w);
+        const bool flip = glv_half_signed<C>(sc, j + (size_t)t * nj, (int)kind, lo, hi);
+        int d = glv_digit<kGlvCBits, kGlvCWin>(lo, hi, (int)w);
+        if (flip) d = -d;
         if (d == 0) return false;
         p = aff_unpack(D[(size_t)((d < 0 ? -d : d) - 1) * drows + j + (size_t)t * nj]);
         neg = d < 0;
@@ -539,8 +597,9 @@ __global__ void __launch_bounds__(kBlock) k_small_msm_glv(const ScalarWords* __r
     auto fetch = [&](uint32_t e, Aff<C>& p, bool& neg) -> bool {
         const uint32_t tt = ipp_term(sp, set, e);
         uint64_t lo, hi;
-        glv_half(sc, tt, kind, lo, hi);
-        const int d = glv_digit<kGlvBits, kGlvWin>(lo, hi, w);
+        const bool flip = glv_half_signed<C>(sc, tt, kind, lo, hi);
+        int d = glv_digit<kGlvBits, kGlvWin>(lo, hi, w);
+        if (flip) d = -d;
         if (d == 0) return false;
         p = aff_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n_all + tt]);
         neg = d < 0;

@@ -40,6 +40,8 @@ struct Bls381 {
                                           0x89759ad4u, 0xaa0d857du, 0x63d4de85u, 0xec024086u, 0x397fe699u, 0x1a0111eau};
     static constexpr uint64_t GLV_LAMBDA[2] = {0x00000000ffffffffull, 0xac45a4010001a402ull};
     static constexpr uint64_t GLV_MLO[2] = {0x63f6e522f6cfee30ull, 0x7c6becf1e01faaddull};
+    static constexpr bool GLV_SIGNED = false;            // both halves are plain 128-bit numbers
+    static constexpr uint64_t GLV_A = 0, GLV_B[2] = {0, 0}, GLV_C[2] = {0, 0}, GLV_M1[2] = {0, 0}, GLV_M2[2] = {0, 0};      // (the lattice form, BN254)
 };
 
 struct Bn254 {
@@ -52,11 +54,23 @@ struct Bn254 {
     static constexpr uint32_t COFACTOR[4] = {1, 0, 0, 0};
     static constexpr uint32_t GX[8] = {0x00000012u, 0xa7000000u, 0x00000013u, 0x61210000u, 0x00000008u, 0xba344d80u, 0x40000001u, 0x25236482u};
     static constexpr uint32_t GY[8] = {0x00000001u, 0, 0, 0, 0, 0, 0, 0};
-    // (the Nogami curve's lambda has 192 bits: a balanced split needs a lattice reduction with signed halves -- not built; the GLV
-    // paths of bp_compact.cuh are compiled for BLS12-381 only)
-    static constexpr bool HAS_GLV = false;
-    static constexpr uint32_t BETA[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    static constexpr uint64_t GLV_LAMBDA[2] = {1, 0};
+    // GLV endomorphism (round 4, second half): phi(x, y) = (BETA x, y) = LAMBDA (x, y) with LAMBDA = 36 u^4 - 1 mod r = -(36 u^3 + 18 u^2 + 6 u + 2)
+    // = 0x9366c48000000005b696800000000013a700000000000016 (190 bits; u = -0x4080000000000001 the curve's parameter).  LAMBDA is far from
+    // sqrt(r), so the split is by the lattice {(x, y): x + y LAMBDA = 0 mod r} with the reduced basis (-A, B), (C, A):
+    //     A = -2u - 1,   B = 6u^2 + 4u + 1,   C = 6u^2 + 2u,   A^2 + B C = r.
+    // With e1 = floor(s A / r) or one less (= (s M1) >> 317, M1 = floor(2^317 A / r)) and e2 = floor(s B / r) or one less (= (s M2) >> 254,
+    // M2 = floor(2^254 B / r)):    s1 = s - e1 A - e2 C  in [0, 2A + 2C) < 2^128,     s2 = e1 B - e2 A  in (-2B, 2A),   s = s1 + s2 LAMBDA mod r.
+    // s2 travels mod 2^128: a value >= 2^66 is a NEGATIVE number (|s2| < 2B < 2^128 - 2^66) -- glv_half_signed in bp_compact.cuh.
+    // Constants and ranges checked with Python integers (3.3e5 scalars incl. the boundaries) and by every parity test over BN254 proofs.
+    static constexpr bool HAS_GLV = true;
+    static constexpr bool GLV_SIGNED = true;
+    static constexpr uint32_t BETA[8] = {0x00000007u, 0xcd800000u, 0x00000006u, 0x49090000u, 0x00000002u, 0x49b36240u, 0x00000000u, 0x00000000u};
+    static constexpr uint64_t GLV_A = 0x8100000000000001ull;
+    static constexpr uint64_t GLV_B[2] = {0x0400000000000003ull, 0x6181800000000002ull};
+    static constexpr uint64_t GLV_C[2] = {0x8500000000000004ull, 0x6181800000000002ull};
+    static constexpr uint64_t GLV_M1[2] = {0x9721b09dbea093a4ull, 0x6f26f94d114d6920ull};
+    static constexpr uint64_t GLV_M2[2] = {0x703acc7fcdafccd5ull, 0xa807eadf812805eeull};
+    static constexpr uint64_t GLV_LAMBDA[2] = {1, 0};     // (the plain-division form is BLS12-381's)
     static constexpr uint64_t GLV_MLO[2] = {0, 0};
 };
 

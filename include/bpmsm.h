@@ -94,9 +94,9 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 1536 terms (and, inside an inner-product proof of 16 .. 4096
                                * generators, for its rounds of up to 8193 terms over precomputed digit multiples) */
 #define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
-#define BP_TUNE_GLV 7         /* 0 (default): that compaction and the rounds after it split every scalar into two 128-bit halves with the curve's
-                               * endomorphism where this build has it (BLS12-381: half the Horner chain, half the host tail); 1 = off.  Proof bytes
-                               * do not depend on it. */
+#define BP_TUNE_GLV 7         /* 0 (default): that compaction and the rounds after it -- and every round of a proof of 1024 .. 4096 generators -- split
+                               * each scalar into two 128-bit halves with the curve's endomorphism (both curves: half the Horner chain, half the
+                               * windows per launch, half the host tail); 1 = off.  Proof bytes do not depend on it. */
 #define BP_TUNE_COMPACT_AT 6  /* inner-product prover (bp_ipp_create, round API): live length at which the folded generators are materialised once
                                * and the remaining rounds run as single launches over their digit multiples, instead of a full-size paired MSM in
                                * every round (/root/reference src/ipp.rs:181-188 folds G, H every round; this is that fold, done once).  0 = automatic
@@ -292,6 +292,11 @@ int bp_fr_inner_product(bp_ctx* ctx, const bp_frvec* a, size_t aoff, const bp_fr
 int bp_fr_hadamard(bp_ctx* ctx, const bp_frvec* a, const bp_frvec* b, bp_frvec** out);
 /* FieldElementVector::scaled_by (src/r1cs/verifier.rs:416). */
 int bp_fr_scaled_by(bp_ctx* ctx, const bp_frvec* a, const uint8_t* s_le32, bp_frvec** out);
+/* out[i] = the two 128-bit halves of a[i] under the curve's GLV endomorphism, as the inner-product prover's kernels split their scalars
+ * (a[i] = s1 + s2 LAMBDA mod r, phi(x, y) = (BETA x, y) = LAMBDA (x, y)): 16 bytes s1, 16 bytes s2, little-endian.  BLS12-381: LAMBDA = z^2 - 1,
+ * both halves plain numbers; BN254: LAMBDA = 36u^4 - 1 mod r (190 bits), s2 is a number mod 2^128 that is NEGATIVE when >= 2^66.  Exposed so
+ * that the split can be checked on its own (tests/test_gpu_ipp.py); no reference counterpart (amcl_wrapper multiplies without it). */
+int bp_fr_glv_split(bp_ctx* ctx, const bp_frvec* a, bp_frvec** out);
 /* FieldElementVector::new_vandermonde_vector(e, n) = [1, e, e^2, ...] (src/ipp.rs:348; src/r1cs/prover.rs:463). */
 int bp_fr_vandermonde(bp_ctx* ctx, const uint8_t* e_le32, size_t n, bp_frvec** out);
 /* VecPoly3::special_inner_product (src/utils/vector_poly.rs:79-97): lhs = (0, l1, l2, l3), rhs = (r0, r1, 0, r3);

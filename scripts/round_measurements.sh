@@ -1,14 +1,14 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 cd $R
-echo "== same-box A/B of the driver's configs (prev = 97a3f53: before the sort / recoding changes)"
+echo "== same-box A/B of the driver's configs (prev = ab/libbpmsm_prev.so, the build named in the log's first line)"; echo "prev = ${AB_PREV:-unnamed}"
 for round in 1 2; do for tag in prev new; do
   if [ $tag = prev ]; then export BPMSM_SO=$R/ab/libbpmsm_prev.so; else unset BPMSM_SO; fi
   python bench.py --steps 10 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['configs']
 print('$tag headline %.3f ms | cfg1 %.2f/%.2f | cfg3 prove %.2f verify %.2f tables %.2f | cfg5 msm %.3f ipp %.2f/%.2f | h2d %.3f' % (d['ms_per_step'], c['cfg1']['create_ms'], c['cfg1']['verify_ms'], c['cfg3_e2e']['prove_ms'], c['cfg3_e2e']['verify_ms'], c['cfg3_e2e']['with_precomputed_generator_tables']['prove_ms'], c['cfg5']['msm_ms'], c['cfg5']['ipp_create_ms'], c['cfg5']['ipp_verify_ms'], d['with_scalar_h2d']['ms_per_step']))"
-done; done 2>&1 | tee gpurun_out/r04_ab_configs_same_box.log
+done; done 2>&1 | tee gpurun_out/${AB_LOG:-r04_ab_configs_same_box.log}
 unset BPMSM_SO
 echo "== ipp profiles"
 bash scripts/prof_ipp.sh r04_ipp_2p16_plain 0 16 none 2>&1 | tail -14
