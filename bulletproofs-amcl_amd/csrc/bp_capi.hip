@@ -896,10 +896,15 @@ int bp_internal_digit_table_build(bp_ctx* ctx, const void* points, size_t n, bp_
     t->d = ctx->pool->get((size_t)rows * n * xz, &t->cap);
     if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     const dim3 grid((unsigned)((n + 63) / 64));
-    if (ctx->curve == BP_CURVE_BLS12_381)
-        hipLaunchKernelGGL(k_digit_table_build<Bls381>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bls381>*)points, (uint32_t)n, (XyzzPacked<Bls381>*)t->d, (uint32_t)rows);
-    else
-        hipLaunchKernelGGL(k_digit_table_build<Bn254>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bn254>*)points, (uint32_t)n, (XyzzPacked<Bn254>*)t->d, (uint32_t)rows);
+    const bool par = (size_t)rows * n <= kDigitTableParMax;                       // small: a lane per (point, multiple), depth 3 + 2 instead of 8
+    const dim3 pgrid((unsigned)(((size_t)rows * n + kBlock - 1) / kBlock));
+    if (ctx->curve == BP_CURVE_BLS12_381) {
+        if (par) hipLaunchKernelGGL(k_digit_table_build_par<Bls381>, pgrid, dim3(kBlock), 0, ctx->stream, (const AffPacked<Bls381>*)points, (uint32_t)n, (XyzzPacked<Bls381>*)t->d, (uint32_t)rows);
+        else hipLaunchKernelGGL(k_digit_table_build<Bls381>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bls381>*)points, (uint32_t)n, (XyzzPacked<Bls381>*)t->d, (uint32_t)rows);
+    } else {
+        if (par) hipLaunchKernelGGL(k_digit_table_build_par<Bn254>, pgrid, dim3(kBlock), 0, ctx->stream, (const AffPacked<Bn254>*)points, (uint32_t)n, (XyzzPacked<Bn254>*)t->d, (uint32_t)rows);
+        else hipLaunchKernelGGL(k_digit_table_build<Bn254>, grid, dim3(64), 0, ctx->stream, (const AffPacked<Bn254>*)points, (uint32_t)n, (XyzzPacked<Bn254>*)t->d, (uint32_t)rows);
+    }
     if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
     *out = t;
     return BP_OK;
@@ -1017,7 +1022,7 @@ static int msm_extras_gh_impl(bp_ctx* ctx, const void* xpts, const void* xsc, si
 static int gh_table_for(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, size_t n, const bp_g1table** T) {
     *T = nullptr;
     const uint32_t lim = ctx->tuning.verify_tables;          // 0 (default): never -- measured slower than the plain MSM on MI355X
-    if (lim < 2 || n < lim || n > G->n || n > H->n || ctx->device_tail || ctx->win_count) return BP_OK;
+    if (lim < 2 || n < lim || n > G->n || n > H->n || ctx->device_tail || ctx->win_count || ctx->pending) return BP_OK;    // (pending: the caller's own bp_msm_g1_begin owns the record buffers)
     return bp_internal_gh_table(ctx, G, H, n, T);
 }
 int bp_internal_gh_ready(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, size_t n, bool* yes) {

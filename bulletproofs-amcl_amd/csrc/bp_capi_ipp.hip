@@ -211,21 +211,27 @@ struct Ipp {
 
     // The 16 affine digit multiples of [G | H | Q] for k_small_msm_glv: a proof of 1024 .. 4096 generators (no compaction) runs ALL its rounds
     // over scalars split in two halves (half the windows per launch, half the doublings in every host tail) when the curve has the split.
-    static int glv_round_table(bp_ipp_state* st) {
+    // affine = false (proofs below 1024 generators): the rows stay packed lazy XYZZ -- no batch inversion, k_small_msm_glv<C, true>
+    static int glv_round_table(bp_ipp_state* st, bool affine) {
         bp_ctx* ctx = st->ctx;
         const size_t m = 2 * st->n0 + 1, rows = kGlvRows;
-        PoolBlock b_mx;
-        if (!b_mx.alloc(ctx, rows * m * sizeof(XyzzPacked<C>))) return BP_ERR_DEVICE;
-        hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const AffPacked<C>*)st->Pall, (uint32_t)m,
-                           (XyzzPacked<C>*)b_mx.p, (uint32_t)rows);
-        HIPCHK(hipGetLastError());
         bp_g1table* t = new (std::nothrow) bp_g1table();
         if (!t) return BP_ERR_DEVICE;
-        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = kGlvBits; t->W = (int)rows; t->digits = true; t->affine = true; t->glv = true;
-        t->d = ctx->pool->get(rows * m * kPt, &t->cap);
-        if (!t->d) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
-        int rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rows * m, (AffPacked<C>*)t->d, ctx->stream, nullptr);
-        if (rc) { bp_internal_table_free(t); return rc; }
+        t->pool = ctx->pool; t->device = ctx->device; t->n = m; t->c = kGlvBits; t->W = (int)rows; t->digits = true; t->affine = affine; t->glv = true;
+        t->d = ctx->pool->get(rows * m * (affine ? kPt : sizeof(XyzzPacked<C>)), &t->cap);
+        PoolBlock b_mx;
+        if (!t->d || (affine && !b_mx.alloc(ctx, rows * m * sizeof(XyzzPacked<C>)))) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+        if (rows * m <= kDigitTableParMax)
+            hipLaunchKernelGGL(k_digit_table_build_par<C>, dim3((unsigned)((rows * m + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const AffPacked<C>*)st->Pall,
+                               (uint32_t)m, (XyzzPacked<C>*)(affine ? b_mx.p : t->d), (uint32_t)rows);
+        else
+            hipLaunchKernelGGL(k_digit_table_build<C>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const AffPacked<C>*)st->Pall, (uint32_t)m,
+                               (XyzzPacked<C>*)(affine ? b_mx.p : t->d), (uint32_t)rows);
+        if (hipGetLastError() != hipSuccess) { bp_internal_table_free(t); return BP_ERR_DEVICE; }
+        if (affine) {
+            int rc = batch_to_affine(ctx, (const XyzzPacked<C>*)b_mx.p, rows * m, (AffPacked<C>*)t->d, ctx->stream, nullptr);
+            if (rc) { bp_internal_table_free(t); return rc; }
+        }
         st->table = t;
         return BP_OK;
     }
@@ -309,8 +315,12 @@ struct Ipp {
         if ((rc = ctx->window_sum.reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
         if ((rc = host_pinned_reserve(ctx, (size_t)2 * R1 * sizeof(XyzzPacked<C>)))) return rc;
         const IppSparse sp = st->n >= 2 ? IppSparse{(uint32_t)st->n0, (uint32_t)st->n, (uint32_t)(st->n / 2)} : IppSparse{0, 0, 0};
-        hipLaunchKernelGGL(k_small_msm_glv<C>, dim3(kGlvWin, 2, splits), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)m,
-                           (const AffPacked<C>*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p, sp);
+        if (st->table->affine)
+            hipLaunchKernelGGL((k_small_msm_glv<C, false>), dim3(kGlvWin, 2, splits), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)m,
+                               (const void*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p, sp);
+        else
+            hipLaunchKernelGGL((k_small_msm_glv<C, true>), dim3(kGlvWin, 2, splits), dim3(kBlock), 0, s, (const ScalarWords*)st->sL, (const ScalarWords*)st->sR, (uint32_t)m,
+                               (const void*)st->table->d, (XyzzPacked<C>*)ctx->window_sum.p, sp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ctx->host_pinned, ctx->window_sum.p, (size_t)2 * R1 * sizeof(XyzzPacked<C>), hipMemcpyDeviceToHost, s));
         bp_prof().lap(1);
@@ -1461,10 +1471,12 @@ int bp_ipp_state_create(bp_ctx* ctx, const bp_g1vec* G, const bp_g1vec* H, const
         // ... from ~4 terms per lane on as AFFINE rows (one batch inversion, ~60 us with its host round trip): the lanes' serial chains are
         // then mixed additions (8M + 2S instead of 12M + 2S per term) -- and, with the scalars split by the curve's endomorphism
         // (BP_TUNE_GLV), 16 multiples for 26 windows of 5 bits per half instead of 8 for 64 windows of 4 bits: k_small_msm_glv
-        // (from 1024 generators on: below, the 16-row table and its inversion cost what the shorter rounds save -- n = 64 1.43-1.53 ms
-        // either way, BN254 n = 512 1.74-1.93 without against 1.93-1.97 with, same box)
-        if (n >= 1024 && ctx->tuning.glv && (ctx->curve == BP_CURVE_BLS12_381 ? Bls381::HAS_GLV : Bn254::HAS_GLV)) {
-            rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::glv_round_table(st) : Ipp<Bn254>::glv_round_table(st);
+        // (from 64 generators on; below 1024 over packed XYZZ rows -- with affine rows the batch inversion's host round trip cost what the
+        // shorter rounds save: n = 64 1.43-1.53 ms either way, BN254 n = 512 1.74-1.93 without against 1.93-1.97 with.  XYZZ rows, same box,
+        // three runs each: BLS12-381 n = 64 1.53-1.75 -> 1.44-1.58 ms, 256 2.23-2.54 -> 2.03-2.19, 512 2.72-3.12 -> 2.39-2.69; BN254 n = 64
+        // 1.08-1.25 -> 1.00-1.09, 512 1.80-1.95 -> 1.62-1.72; n = 16 equal)
+        if (n >= 64 && ctx->tuning.glv && (ctx->curve == BP_CURVE_BLS12_381 ? Bls381::HAS_GLV : Bn254::HAS_GLV)) {
+            rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::glv_round_table(st, n >= 1024) : Ipp<Bn254>::glv_round_table(st, n >= 1024);
         } else {
             rc = bp_internal_digit_table_build(ctx, st->Pall, 2 * n + 1, &st->table);
             if (!rc && n >= 1024) rc = ctx->curve == BP_CURVE_BLS12_381 ? Ipp<Bls381>::digit_table_to_affine(ctx, st->table) : Ipp<Bn254>::digit_table_to_affine(ctx, st->table);

@@ -583,9 +583,11 @@ __global__ void __launch_bounds__(kBlock) k_compact_merge_halves(const XyzzPacke
 // mult[(m - 1) * n + t] = m P_t (affine, 16 multiples) for both kinds; phi is applied once to the block's finished sum of a kind-1 block --
 // and leaves one record at bit position 5 w: window_sum[(set * kGlvWin + w) * gridDim.z + z].  sc1 / sc2: the round's two scalar sets,
 // decomposed.  gridDim.z is even.
-template <class C>
+// XROWS: `mult` holds packed lazy XYZZ rows instead of affine ones (small proofs: the batch inversion that makes rows affine costs a host
+// round trip, more than the mixed additions save when a lane has one or two terms) -- full additions, as k_small_msm<C, 1>.
+template <class C, bool XROWS>
 __global__ void __launch_bounds__(kBlock) k_small_msm_glv(const ScalarWords* __restrict__ sc1, const ScalarWords* __restrict__ sc2, uint32_t n_all,
-                                                          const AffPacked<C>* __restrict__ mult, XyzzPacked<C>* __restrict__ window_sum, IppSparse sp) {
+                                                          const void* __restrict__ mult_rows, XyzzPacked<C>* __restrict__ window_sum, IppSparse sp) {
     using Fp = typename C::Fp;
     __shared__ XyzzPacked<C> lds[kBlock];
     const int w = blockIdx.x, set = blockIdx.y, kind = blockIdx.z & 1;
@@ -594,6 +596,29 @@ __global__ void __launch_bounds__(kBlock) k_small_msm_glv(const ScalarWords* __r
     const uint32_t n = sp.live ? sp.n0 + 1 : n_all;             // the lanes walk the terms that can be non-zero (IppSparse, bp_kernels.cuh)
     uint32_t t = (blockIdx.z >> 1) * kBlock + threadIdx.x;
     XyzzLazy<C> mine = xyzz_lazy_inf<C>();
+    if constexpr (XROWS) {
+        const XyzzPacked<C>* mult = (const XyzzPacked<C>*)mult_rows;
+#pragma unroll 1
+        for (; t < n; t += stride) {
+            const uint32_t tt = ipp_term(sp, set, t);
+            uint64_t lo, hi;
+            const bool flip = glv_half_signed<C>(sc, tt, kind, lo, hi);
+            int d = glv_digit<kGlvBits, kGlvWin>(lo, hi, w);
+            if (flip) d = -d;
+            if (d == 0) continue;
+            XyzzLazy<C> acc = xyzz_lazy_unpack(mult[(size_t)((d < 0 ? -d : d) - 1) * n_all + tt]);
+            if (d < 0 && !acc.inf) acc.y = feb_neg<4>(acc.y);
+            mine = xyzz_lazy_add(mine, acc);
+        }
+        const uint32_t per = (n + (gridDim.z >> 1) - 1) / (gridDim.z >> 1);      // lanes of this block that can hold a term
+        mine = block_tree_sum_quad<C>(mine, lds, per < (uint32_t)kBlock ? (int)per : kBlock);
+        if (threadIdx.x == 0) {
+            if (kind) xyzz_lazy_phi<C>(mine);
+            window_sum[((size_t)set * kGlvWin + w) * gridDim.z + blockIdx.z] = xyzz_lazy_pack(mine);
+        }
+        return;
+    }
+    const AffPacked<C>* mult = (const AffPacked<C>*)mult_rows;
     auto fetch = [&](uint32_t e, Aff<C>& p, bool& neg) -> bool {
         const uint32_t tt = ipp_term(sp, set, e);
         uint64_t lo, hi;

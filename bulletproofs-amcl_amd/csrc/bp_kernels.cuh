@@ -1005,6 +1005,27 @@ __global__ void __launch_bounds__(kBlock) k_digit_table_build(const AffPacked<C>
     }
 }
 
+// The same table with a lane per (point, multiple): m P by double-and-add from P -- at most 4 doublings + 3 additions deep for m <= 16
+// where the serial form above chains `rows` additions per lane.  For SMALL vectors (rows * n lanes fit the chip once): the build sits on
+// the critical path of a small proof's state creation, and there the depth is what costs, not the ~3x as many point operations.
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_digit_table_build_par(const AffPacked<C>* __restrict__ pts, uint32_t n, XyzzPacked<C>* __restrict__ mult,
+                                                                  uint32_t rows) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * rows) return;
+    const uint32_t m = idx / n + 1, t = idx - (m - 1) * n;
+    const Aff<C> p = aff_unpack(pts[t]);
+    XyzzLazy<C> acc = xyzz_lazy_inf<C>();
+    xyzz_lazy_add_aff(acc, p);                                    // (identity rows stay the identity)
+#pragma unroll 1
+    for (int i = 30 - __clz((int)m); i >= 0; i--) {               // bits below the leading one
+        acc = xyzz_lazy_dbl(acc);
+        if ((m >> i) & 1) xyzz_lazy_add_aff(acc, p);
+    }
+    mult[(size_t)(m - 1) * n + t] = xyzz_lazy_pack(acc);
+}
+constexpr uint32_t kDigitTableParMax = 32768;                    // lanes up to which the parallel form is used
+
 // The terms of an inner-product round that CAN be non-zero.  A round's scalar set over [G (n0) | H (n0) | Q] is zero on half of the
 // generators by construction (bp_ipp.cuh: L takes the G_k with k mod live >= h and the H_k with k mod live < h, R the other halves),
 // so a lane that walks all 2 n0 + 1 terms spends half of its serial steps skipping zeros -- whole waves at a time in the first

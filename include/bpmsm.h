@@ -94,7 +94,7 @@ int bp_ctx_set_window_bits(bp_ctx* ctx, int c);
 #define BP_TUNE_SMALL_MSM 4   /* 1 (default) / 0: single-launch path for n <= 1536 terms (and, inside an inner-product proof of 16 .. 4096
                                * generators, for its rounds of up to 8193 terms over precomputed digit multiples) */
 #define BP_TUNE_TAIL_CHAINS 5 /* host tail: independent Horner walks on helper threads, 1 .. 16 (0: 4 when a fold has >= 48 records, 8 / 16 for several shards' sets, else 1) */
-#define BP_TUNE_GLV 7         /* 0 (default): that compaction and the rounds after it -- and every round of a proof of 1024 .. 4096 generators -- split
+#define BP_TUNE_GLV 7         /* 0 (default): that compaction and the rounds after it -- and every round of a proof of 64 .. 4096 generators -- split
                                * each scalar into two 128-bit halves with the curve's endomorphism (both curves: half the Horner chain, half the
                                * windows per launch, half the host tail); 1 = off.  Proof bytes do not depend on it. */
 #define BP_TUNE_COMPACT_AT 6  /* inner-product prover (bp_ipp_create, round API): live length at which the folded generators are materialised once
