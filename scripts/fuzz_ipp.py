@@ -12,7 +12,7 @@ ctxs = {0: bp.Context(0, 0), 1: bp.Context(1, 0)}
 t_end, cases, fails = time.time() + budget, 0, 0
 while time.time() < t_end:
     cid = rnd.randrange(2); ctx = ctxs[cid]; r = ctx.r
-    n = rnd.choice([1, 2, 4, 8, 16, 32, 64, 128, 256, 512])         # >= 256: the rounds leave the single-launch path; tables can engage
+    n = rnd.choice([1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 64, 256, 1024, 2048])      # >= 256: tables can engage; 64 .. 512: split rounds over XYZZ rows; >= 1024: over affine rows
     ctx.set_ipp_fold_generators(rnd.random() < 0.3)
     seed = rnd.randrange(1 << 30)
     Gv = bp.G1Vector.fixed_base(ctx, bp.FieldElementVector.from_bytes(ctx, O.random_scalars(cid, seed, n), n))
