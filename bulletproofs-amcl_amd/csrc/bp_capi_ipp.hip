@@ -62,6 +62,8 @@ struct bp_r1cs_plan {
     int device, curve;
     size_t n, m, nq, nterms, ndest, nheavy;
     void *seg, *tq, *coeff, *heavy;     // uint32[ndest + 1], uint32[nterms], ScalarWords[nterms], uint32[nheavy]
+    size_t nchunks = 0;                 // heavy destinations cut into chunks of <= kFlattenChunk terms (k_r1cs_flatten_heavy)
+    void *chunk = nullptr, *hfirst = nullptr;   // uint32[2 nchunks] (first, end term of a chunk), uint32[nheavy + 1] (first chunk of a heavy destination)
 };
 
 namespace {
@@ -801,18 +803,20 @@ static int r1cs_verifier_scalars_impl(bp_ctx* ctx, Transcript& t, const uint8_t*
 template <class C>
 static int flattened_constraints_impl(bp_ctx* ctx, const bp_r1cs_plan* p, const uint8_t* z_le32, bp_frvec* outv[4], uint8_t* wc_le32) {
     using F = typename C::Fr;
-    PoolBlock b_zp, b_all;
-    if (!b_zp.alloc(ctx, (p->nq ? p->nq : 1) * 32) || !b_all.alloc(ctx, p->ndest * 32)) return BP_ERR_DEVICE;
+    PoolBlock b_zp, b_all, b_part;
+    if (!b_zp.alloc(ctx, (p->nq ? p->nq : 1) * 32) || !b_all.alloc(ctx, p->ndest * 32) || !b_part.alloc(ctx, (p->nchunks ? p->nchunks : 1) * 32)) return BP_ERR_DEVICE;
     void *zp = b_zp.p, *all = b_all.p;
     auto cleanup = [&]() {};
     hipStream_t s = ctx->stream;
     if (p->nq) hipLaunchKernelGGL(k_fr_powers_mont<C>, dim3(blocks_for(p->nq)), dim3(kBlock), 0, s, fr_mont_words<F>(fr_from_le<F>(z_le32)), p->nq, (ScalarWords*)zp);
     hipLaunchKernelGGL(k_r1cs_flatten<C>, dim3(blocks_for(p->ndest)), dim3(kBlock), 0, s, (const uint32_t*)p->seg, (const uint32_t*)p->tq,
                        (const ScalarWords*)p->coeff, (const ScalarWords*)zp, (uint32_t)(3 * p->n), (uint32_t)p->ndest, kFlattenLightMax, (ScalarWords*)all);
-    if (p->nheavy)
-        hipLaunchKernelGGL(k_r1cs_flatten_heavy<C>, dim3((unsigned)(p->nheavy < 1024 ? p->nheavy : 1024)), dim3(kBlock), 0, s, (const uint32_t*)p->heavy,
-                           (uint32_t)p->nheavy, (const uint32_t*)p->seg, (const uint32_t*)p->tq, (const ScalarWords*)p->coeff, (const ScalarWords*)zp,
-                           (uint32_t)(3 * p->n), (ScalarWords*)all);
+    if (p->nheavy) {
+        hipLaunchKernelGGL(k_r1cs_flatten_heavy<C>, dim3((unsigned)(p->nchunks < 2048 ? p->nchunks : 2048)), dim3(kBlock), 0, s, (const uint32_t*)p->chunk,
+                           (uint32_t)p->nchunks, (const uint32_t*)p->tq, (const ScalarWords*)p->coeff, (const ScalarWords*)zp, (ScalarWords*)b_part.p);
+        hipLaunchKernelGGL(k_r1cs_flatten_heavy_final<C>, dim3(blocks_for(p->nheavy)), dim3(kBlock), 0, s, (const uint32_t*)p->heavy, (const uint32_t*)p->hfirst,
+                           (uint32_t)p->nheavy, (const ScalarWords*)b_part.p, (uint32_t)(3 * p->n), (ScalarWords*)all);
+    }
     if (hipGetLastError() != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
     const size_t lens[4] = {p->n, p->n, p->n, p->m}, offs[4] = {0, p->n, 2 * p->n, 3 * p->n};
     int rc = BP_OK;
@@ -1647,19 +1651,33 @@ int bp_r1cs_plan_create(bp_ctx* ctx, size_t n_terms, const uint32_t* term_constr
         tq[pos] = term_constraint[t];
         memcpy(&coeff[(size_t)pos * 32], coeff_le32 + 32 * t, 32);
     }
-    for (size_t d = 0; d < ndest; d++) if (seg[d + 1] - seg[d] > kFlattenLightMax) heavy.push_back((uint32_t)d);
+    std::vector<uint32_t> chunk, hfirst;
+    for (size_t d = 0; d < ndest; d++) {
+        if (seg[d + 1] - seg[d] <= kFlattenLightMax) continue;
+        heavy.push_back((uint32_t)d);
+        hfirst.push_back((uint32_t)(chunk.size() / 2));
+        for (uint32_t lo = seg[d]; lo < seg[d + 1]; lo += kFlattenChunk) {
+            chunk.push_back(lo);
+            chunk.push_back(seg[d + 1] - lo > kFlattenChunk ? lo + kFlattenChunk : seg[d + 1]);
+        }
+    }
+    hfirst.push_back((uint32_t)(chunk.size() / 2));
     int rc = bp_internal_set_device(ctx); if (rc) return rc;
     bp_r1cs_plan* p = new (std::nothrow) bp_r1cs_plan{ctx->device, ctx->curve, n, m, n_constraints, n_terms, ndest, heavy.size(), nullptr, nullptr, nullptr, nullptr};
     if (!p) return BP_ERR_DEVICE;
+    p->nchunks = chunk.size() / 2;
     auto fail = [&]() { bp_r1cs_plan_free(p); return BP_ERR_DEVICE; };
     if (hipMalloc(&p->seg, (ndest + 1) * 4) != hipSuccess || hipMalloc(&p->tq, tq.size() * 4) != hipSuccess ||
-        hipMalloc(&p->coeff, coeff.size()) != hipSuccess || hipMalloc(&p->heavy, (heavy.size() ? heavy.size() : 1) * 4) != hipSuccess)
+        hipMalloc(&p->coeff, coeff.size()) != hipSuccess || hipMalloc(&p->heavy, (heavy.size() ? heavy.size() : 1) * 4) != hipSuccess ||
+        hipMalloc(&p->chunk, (chunk.size() ? chunk.size() : 1) * 4) != hipSuccess || hipMalloc(&p->hfirst, hfirst.size() * 4) != hipSuccess)
         return fail();
     hipStream_t s = ctx->stream;
     if (hipMemcpyAsync(p->seg, seg.data(), (ndest + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(p->tq, tq.data(), tq.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(p->coeff, coeff.data(), coeff.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
         (heavy.size() && hipMemcpyAsync(p->heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        (chunk.size() && hipMemcpyAsync(p->chunk, chunk.data(), chunk.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        hipMemcpyAsync(p->hfirst, hfirst.data(), hfirst.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return fail();
     *out = p;
@@ -1671,7 +1689,7 @@ int bp_r1cs_plan_free(bp_r1cs_plan* p) {
     return bp_guard([&]() -> int {
     if (!p) return BP_OK;
     (void)hipSetDevice(p->device);
-    for (void* b : {p->seg, p->tq, p->coeff, p->heavy}) if (b) (void)hipFree(b);
+    for (void* b : {p->seg, p->tq, p->coeff, p->heavy, p->chunk, p->hfirst}) if (b) (void)hipFree(b);
     delete p;
     return BP_OK;
     });

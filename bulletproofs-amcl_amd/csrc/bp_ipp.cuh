@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(kBlock) k_r1cs_verifier_scalars(const ScalarWo
 // and each proof evaluates  out[d] = +- sum_t zp[q_t] coeff_t  with zp[q] = z^(q+1).
 //   k_fr_powers_mont      zp[q] = z^(q+1), Montgomery form
 //   k_r1cs_flatten        lane per destination with at most `light_max` terms
-//   k_r1cs_flatten_heavy  block per destination with more (the constant term collects one term per constraint that has one)
+//   k_r1cs_flatten_heavy  (+ _final) destinations with more, cut into chunks of 2048 terms (the constant term collects one term per constraint that has one)
 template <class C>
 __global__ void __launch_bounds__(kBlock) k_fr_powers_mont(ScalarWords z_mont, size_t nq, ScalarWords* __restrict__ zp) {
     using F = typename C::Fr;
@@ -332,20 +332,36 @@ __global__ void __launch_bounds__(kBlock) k_r1cs_flatten(const uint32_t* __restr
     fr_store<F>(out, d, d >= n3 ? fe_neg(acc) : acc);
 }
 
+// A heavy destination is cut into chunks of <= kFlattenChunk terms at plan creation (round 4: the constant term of BASELINE config 3
+// collects 136 192 terms -- one block walked them alone in 0.32 ms, in the prover AND the verifier): block per chunk c, terms
+// [chunk[2c], chunk[2c + 1]) -> partial[c]; then a lane per heavy destination adds its chunks' partial sums.
+constexpr uint32_t kFlattenChunk = 2048;
 template <class C>
-__global__ void __launch_bounds__(kBlock) k_r1cs_flatten_heavy(const uint32_t* __restrict__ heavy, uint32_t nheavy, const uint32_t* __restrict__ seg,
-                                                               const uint32_t* __restrict__ tq, const ScalarWords* __restrict__ coeff,
-                                                               const ScalarWords* __restrict__ zp, uint32_t n3, ScalarWords* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_r1cs_flatten_heavy(const uint32_t* __restrict__ chunk, uint32_t nchunks, const uint32_t* __restrict__ tq,
+                                                               const ScalarWords* __restrict__ coeff, const ScalarWords* __restrict__ zp,
+                                                               ScalarWords* __restrict__ partial) {
     using F = typename C::Fr;
     __shared__ ScalarWords lds[kBlock];
-    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const uint32_t d = heavy[h], lo = seg[d], hi = seg[d + 1];
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t lo = chunk[2 * c], hi = chunk[2 * c + 1];
         Fe<F> acc = fe_zero<F>();
         for (uint32_t t = lo + threadIdx.x; t < hi; t += kBlock) acc = fe_add(acc, fe_mul(fr_load<F>(zp, tq[t]), fr_load<F>(coeff, t)));
         acc = block_fr_sum<F>(acc, lds);
-        if (threadIdx.x == 0) fr_store<F>(out, d, d >= n3 ? fe_neg(acc) : acc);
+        if (threadIdx.x == 0) fr_store<F>(partial, c, acc);
         __syncthreads();
     }
+}
+// hfirst[h] .. hfirst[h + 1]: the chunks of heavy destination h
+template <class C>
+__global__ void __launch_bounds__(kBlock) k_r1cs_flatten_heavy_final(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ hfirst, uint32_t nheavy,
+                                                                     const ScalarWords* __restrict__ partial, uint32_t n3, ScalarWords* __restrict__ out) {
+    using F = typename C::Fr;
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nheavy) return;
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t c = hfirst[h]; c < hfirst[h + 1]; c++) acc = fe_add(acc, fr_load<F>(partial, c));
+    const uint32_t d = heavy[h];
+    fr_store<F>(out, d, d >= n3 ? fe_neg(acc) : acc);
 }
 
 // ---------------------------------------------------------------------------------------------- IPP round
