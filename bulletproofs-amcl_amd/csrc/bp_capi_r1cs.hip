@@ -175,6 +175,7 @@ struct R1cs {
     struct Phase {
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         std::string log;
+        const char* who = "prove";
         void lap(bp_ctx* ctx, const char* what) {
             if (!bp_profile_on()) return;
             (void)hipStreamSynchronize(ctx->stream);
@@ -184,7 +185,7 @@ struct R1cs {
             log += b;
             t0 = t1;
         }
-        ~Phase() { if (bp_profile_on() && !log.empty()) fprintf(stderr, "[bpmsm profile] r1cs prove us:%s\n", log.c_str()); }
+        ~Phase() { if (bp_profile_on() && !log.empty()) fprintf(stderr, "[bpmsm profile] r1cs %s us:%s\n", who, log.c_str()); }
     };
 
     // single phase: bl = i1 o1 s1 t1 t3 t4 t5 t6
@@ -337,6 +338,8 @@ struct R1cs {
     static int verify_tail(bp_ctx* ctx, bp_transcript* t, const bp_r1cs_plan* plan, const bp_g1vec* G, const bp_g1vec* H, const uint8_t* g_le,
                            const uint8_t* h_le, const uint8_t* V_le, size_t n1, size_t n, size_t m, const uint8_t* proof, const uint8_t* r_le32) {
         Temps T;
+        Phase vph;
+        vph.who = "verify";
         const int cv = ctx->curve;
         const size_t pn = padded_len(n), lg = lg_of(pn);
         const uint8_t* P = proof;
@@ -358,8 +361,10 @@ struct R1cs {
         uint8_t zle[32], xle[32], ule[32], yile[32], wcle[32];
         fr_out<F>(z, zle); fr_out<F>(x, xle); fr_out<F>(u, ule);
         bp_frvec* w[4] = {};
+        vph.lap(ctx, "transcript + challenges");
         RC(bp_r1cs_flattened_constraints(ctx, plan, zle, w, wcle));                                            // :329
         for (auto* v : w) T.keep(v);
+        vph.lap(ctx, "flattened_constraints");
         const Fe<F> wc = fr_in<F>(wcle), a = fr_in<F>(ab), b = fr_in<F>(ab + 32);
         const Fe<F> y_inv = fe_inv<F>(y);
         fr_out<F>(y_inv, yile);
@@ -371,11 +376,13 @@ struct R1cs {
         uint8_t dle[32];
         RC(bp_fr_inner_product(ctx, ywr, 0, w[0], 0, n, dle));                                                 // delta, :344-352
         const Fe<F> delta = fr_in<F>(dle);
+        vph.lap(ctx, "delta");
         std::vector<uint8_t> usq(lg * 32 + 32), uisq(lg * 32 + 32);
         bp_frvec *g_sc = nullptr, *h_sc = nullptr;
         RC(bp_r1cs_verifier_scalars(ctx, t, Lp, Rp, lg, pn, n1, w[0], w[1], w[2], yile, xle, ule, ab, ab + 32, usq.data(), uisq.data(), &g_sc, &h_sc));   // :354-390
         T.keep(g_sc);
         T.keep(h_sc);
+        vph.lap(ctx, "verifier scalars");
         const Fe<F> r = fr_in<F>(r_le32);                                                                      // :392
         const Fe<F> x2 = fe_sqr(x), x3 = fe_mul(x2, x);
         const Fe<F> tx = fr_in<F>(S), txb = fr_in<F>(S + 32), eb = fr_in<F>(S + 64);
@@ -432,6 +439,7 @@ struct R1cs {
         bp_g1vec* d_hp = nullptr;
         RCV(bp_g1vec_upload(ctx, hp.data(), nx, BP_FMT_LE, &d_hp));
         T.keep(d_hp);
+        vph.lap(ctx, "term assembly + uploads");
         uint8_t res[pb];
         bool done = false;
         if (tabled) RC(bp_internal_msm_extras_gh(ctx, d_hp->d, sc->d, nx, (const uint8_t*)sc->d + nx * 32, G, H, pn, res, &done));
@@ -444,6 +452,7 @@ struct R1cs {
             HIPCHK(hipMemcpyAsync((uint8_t*)pts->d + (nx + pn) * row, H->d, pn * row, hipMemcpyDeviceToDevice, s));
             RC(bp_msm_g1(ctx, pts, sc, res));                                                                  // :448
         }
+        vph.lap(ctx, "msm");
         for (size_t k = 0; k < pb; k++) if (res[k]) return BP_ERR_VERIFY;                                       // !res.is_identity(), :449-451
         return BP_OK;
     }
