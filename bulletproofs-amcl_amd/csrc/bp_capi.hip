@@ -1476,6 +1476,31 @@ int bp_frvec_upload(bp_ctx* ctx, const uint8_t* scalars_le32, size_t n, bp_frvec
     });
 }
 
+// `bytes` of LIBRARY-made host data -> device memory on the context's stream without waiting for it: through the page-locked ring (a
+// pageable source makes hipMemcpyAsync stage the bytes synchronously, ~10 us per call; the verifiers issue four or five such copies per
+// proof).  Larger than a quarter of the ring: a plain copy and a synchronisation (the source may be a temporary of the caller).
+int bp_internal_stage_h2d(bp_ctx* ctx, const void* src, size_t bytes, void* dst) {
+    constexpr size_t kStage = (size_t)1 << 20;
+    if (bytes == 0) return BP_OK;
+    if (!ctx->stage && hipHostMalloc(&ctx->stage, kStage, hipHostMallocDefault) == hipSuccess) { ctx->stage_cap = kStage; ctx->stage_cur = 0; }
+    if (!ctx->stage || bytes > kStage / 4) {
+        (void)hipGetLastError();
+        if (!ctx->stage) ctx->stage = nullptr;
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return BP_OK;
+    }
+    if (ctx->stage_cur + bytes > ctx->stage_cap) {          // wrap: everything staged so far must have left the ring
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->stage_cur = 0;
+    }
+    uint8_t* slot = (uint8_t*)ctx->stage + ctx->stage_cur;
+    ctx->stage_cur += (bytes + 63) & ~(size_t)63;
+    memcpy(slot, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return BP_OK;
+}
+
 int bp_internal_frvec_upload_trusted(bp_ctx* ctx, const uint8_t* le32, size_t n, bp_frvec** out) {
     constexpr size_t kStage = (size_t)1 << 20;
     const size_t bytes = n * 32;

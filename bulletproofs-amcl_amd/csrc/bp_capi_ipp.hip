@@ -585,51 +585,46 @@ struct Ipp {
         bool tabled = false;
         if ((rc = bp_internal_gh_ready(ctx, G, H, n, &tabled))) return rc;
         const size_t nx = 1 + 2 * lg_n;
-        PoolBlock b_pts, b_sc, b_chd, b_raw;      // recycled through the context's pool (no hipMalloc / hipFree per proof)
-        if (!b_pts.alloc(ctx, (tabled ? nx : m) * kPt) || !b_sc.alloc(ctx, (m + (tabled ? nx : 0)) * 32) || !b_chd.alloc(ctx, (2 * lg_n + 1) * 32) ||
-            !b_raw.alloc(ctx, (2 * lg_n + 1) * 2 * kFb))
-            return BP_ERR_DEVICE;
-        void *pts = b_pts.p, *sc = b_sc.p, *chd = b_chd.p, *raw = b_raw.p;
-        auto cleanup = [&]() {};
+        // what the host made -- challenges (Montgomery form), the proof's points, the head / tail scalars -- travels as ONE staged copy
+        const size_t o_raw = (2 * lg_n + 1) * 32, o_ends = o_raw + nx * 2 * kFb, in_bytes = o_ends + nx * 32;
+        PoolBlock b_pts, b_sc, b_in;              // recycled through the context's pool (no hipMalloc / hipFree per proof)
+        if (!b_pts.alloc(ctx, (tabled ? nx : m) * kPt) || !b_sc.alloc(ctx, (m + (tabled ? nx : 0)) * 32) || !b_in.alloc(ctx, in_bytes)) return BP_ERR_DEVICE;
+        void *pts = b_pts.p, *sc = b_sc.p, *chd = b_in.p, *raw = (uint8_t*)b_in.p + o_raw;
+        const ScalarWords* d_ends = (const ScalarWords*)((uint8_t*)b_in.p + o_ends);
         if ((rc = ctx->flags.reserve(ctx, 64))) return rc;
         uint32_t* flag = (uint32_t*)ctx->flags.p;     // Q, L, R come from the proof: validated (on the curve, canonical)
         uint32_t host_flag = 0;
-        // challenges (Montgomery form) for the per-element products
-        std::vector<ScalarWords> hch(2 * lg_n + 1);
+        std::vector<uint8_t> hin(in_bytes);
+        ScalarWords* hch = (ScalarWords*)hin.data();                                     // challenges for the per-element products
         for (size_t j = 0; j < lg_n; j++) { hch[j] = fr_mont_words<F>(ch[j]); hch[lg_n + j] = fr_mont_words<F>(ch_inv[j]); }
+        memset(&hch[2 * lg_n], 0, 32);
         Fe<F> a = fr_from_le<F>(a_le), b = fr_from_le<F>(b_le);
+        // points Q, L_vec, R_vec -> resident form                                       :244-249
+        uint8_t* hraw = hin.data() + o_raw;
+        memcpy(hraw, Q_le, 2 * kFb);
+        if (lg_n) { memcpy(hraw + 2 * kFb, L_le, lg_n * 2 * kFb); memcpy(hraw + (1 + lg_n) * 2 * kFb, R_le, lg_n * 2 * kFb); }
         // head and tail scalars: a*b, -u_j^2, -u_j^-2 (canonical)                      :234-242
-        std::vector<ScalarWords> ends(1 + 2 * lg_n);
-        { uint32_t w[8]; fe_pack_words<F>(w, fe_from_mont<F>(fe_mul(a, b))); memcpy(ends[0].w, w, 32); }
+        uint8_t* ends = hin.data() + o_ends;
+        { uint32_t w[8]; fe_pack_words<F>(w, fe_from_mont<F>(fe_mul(a, b))); memcpy(ends, w, 32); }
         for (size_t j = 0; j < lg_n; j++) {
             uint32_t w[8];
-            fe_pack_words<F>(w, fe_from_mont<F>(fe_neg(fe_sqr(ch[j])))); memcpy(ends[1 + j].w, w, 32);
-            fe_pack_words<F>(w, fe_from_mont<F>(fe_neg(fe_sqr(ch_inv[j])))); memcpy(ends[1 + lg_n + j].w, w, 32);
+            fe_pack_words<F>(w, fe_from_mont<F>(fe_neg(fe_sqr(ch[j])))); memcpy(ends + (1 + j) * 32, w, 32);
+            fe_pack_words<F>(w, fe_from_mont<F>(fe_neg(fe_sqr(ch_inv[j])))); memcpy(ends + (1 + lg_n + j) * 32, w, 32);
         }
-        // points Q, L_vec, R_vec -> resident form                                       :244-249
-        std::vector<uint8_t> hraw((2 * lg_n + 1) * 2 * kFb);
-        memcpy(hraw.data(), Q_le, 2 * kFb);
-        if (lg_n) { memcpy(hraw.data() + 2 * kFb, L_le, lg_n * 2 * kFb); memcpy(hraw.data() + (1 + lg_n) * 2 * kFb, R_le, lg_n * 2 * kFb); }
         hipStream_t s = ctx->stream;
-        bool ok = hipMemsetAsync(flag, 0, 4, s) == hipSuccess &&
-                  hipMemcpyAsync(chd, hch.data(), 2 * lg_n * 32 + 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(sc, ends.data(), 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  (lg_n == 0 || hipMemcpyAsync((uint8_t*)sc + (1 + 2 * n) * 32, ends.data() + 1, 2 * lg_n * 32, hipMemcpyHostToDevice, s) == hipSuccess);
-        if (!ok) { cleanup(); return BP_ERR_DEVICE; }
+        if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) return BP_ERR_DEVICE;
+        if ((rc = bp_internal_stage_h2d(ctx, hin.data(), in_bytes, b_in.p))) return rc;
         if (tabled) {
-            // [Q | L | R] -> pts[0 .. nx), their scalars -> sc[m .. m + nx); the generators' scalars -> sc[1 .. 1 + 2n)
-            void* xs = (uint8_t*)sc + m * 32;
-            if (hipMemcpyAsync(xs, ends.data(), nx * 32, hipMemcpyHostToDevice, s) != hipSuccess) return BP_ERR_DEVICE;
+            // [Q | L | R] -> pts[0 .. nx), their scalars = d_ends; the generators' scalars -> sc[1 .. 1 + 2n)
             hipLaunchKernelGGL(k_points_to_resident<C>, dim3(blocks_for(nx)), dim3(kBlock), 0, s, (const uint32_t*)raw, nx, (AffPacked<C>*)pts, flag);
             if (hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return BP_ERR_DEVICE;
             hipLaunchKernelGGL(k_ipp_verify_terms<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
                                (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, (const ScalarWords*)chd, (const ScalarWords*)chd + lg_n, (int)lg_n,
-                               fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)nullptr, (ScalarWords*)sc);
+                               fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)nullptr, (ScalarWords*)sc, (const ScalarWords*)nullptr, (ScalarWords*)nullptr);
             if (hipGetLastError() != hipSuccess) return BP_ERR_DEVICE;
             uint8_t expect[2 * kFb];
             bool done = false;
-            rc = bp_internal_msm_extras_gh(ctx, pts, xs, nx, (const uint8_t*)sc + 32, G, H, n, expect, &done);   // synchronises both streams
+            rc = bp_internal_msm_extras_gh(ctx, pts, d_ends, nx, (const uint8_t*)sc + 32, G, H, n, expect, &done);   // synchronises both streams
             if (rc) return rc;
             if (!done) return BP_ERR_DEVICE;                                                // bp_internal_gh_ready said yes
             if (host_flag) return BP_ERR_VERIFY;
@@ -643,8 +638,8 @@ struct Ipp {
         if (hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return BP_ERR_DEVICE;
         hipLaunchKernelGGL(k_ipp_verify_terms<C>, dim3(blocks_for(n)), dim3(kBlock), 0, s, (const AffPacked<C>*)G->d, (const AffPacked<C>*)H->d,
                            (const ScalarWords*)Gf->d, (const ScalarWords*)Hf->d, (const ScalarWords*)chd, (const ScalarWords*)chd + lg_n, (int)lg_n,
-                           fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)pts, (ScalarWords*)sc);
-        if (hipGetLastError() != hipSuccess) { cleanup(); return BP_ERR_DEVICE; }
+                           fr_mont_words<F>(a), fr_mont_words<F>(b), n, (AffPacked<C>*)pts, (ScalarWords*)sc, d_ends, (ScalarWords*)sc + 1 + 2 * n);
+        if (hipGetLastError() != hipSuccess) return BP_ERR_DEVICE;
         uint8_t expect[2 * kFb];
         rc = bp_internal_msm(ctx, pts, sc, m, expect);                                  // :251-253
         if (hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : BP_ERR_DEVICE;

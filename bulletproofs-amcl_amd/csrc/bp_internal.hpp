@@ -300,6 +300,7 @@ int bp_internal_set_device(const bp_ctx* ctx);
 // n canonical scalars the LIBRARY produced (challenges, their powers, blinding combinations) -> a resident vector, without the
 // canonicity check and without waiting for the stream (the bytes are staged in the context's page-locked ring)
 extern "C" int bp_internal_frvec_upload_trusted(bp_ctx* ctx, const uint8_t* le32, size_t n, bp_frvec** out);
+extern "C" int bp_internal_stage_h2d(bp_ctx* ctx, const void* src, size_t bytes, void* dst);      // library-made host bytes -> device, through the pinned ring (no wait)
 // a few two-term commitments k1 g + k2 h on the host (bp_capi.hip)
 // The verifiers' single check  out = <xsc, xpts> + <gh_sc, [G[0 .. n) | H[0 .. n)]>  with the [G | H] part over the vectors' window tables
 // (merged-window pipeline on ctx's stream) and the nx other terms (proof points, commitments) as their own MSM on a sibling stream, one

@@ -611,10 +611,13 @@ __global__ void __launch_bounds__(kBlock) k_ipp_verify_terms(const AffPacked<C>*
                                                              const ScalarWords* __restrict__ gf, const ScalarWords* __restrict__ hf,
                                                              const ScalarWords* __restrict__ ch, const ScalarWords* __restrict__ ch_inv, int lg_n,
                                                              ScalarWords a_mont, ScalarWords b_mont, size_t n, AffPacked<C>* __restrict__ pts,
-                                                             ScalarWords* __restrict__ sc) {
+                                                             ScalarWords* __restrict__ sc, const ScalarWords* __restrict__ ends, ScalarWords* __restrict__ ends_to) {
     using F = typename C::Fr;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // the 1 + 2 lg n scalars the host computed (a b on Q, -u_j^2 on L_j, -u_j^-2 on R_j) travel in the same upload as the challenges: the
+    // first of them goes to sc[0], the others to ends_to[0 ..) (= sc[1 + 2n ..) of the plain layout)
+    if (ends) for (size_t j = i; j < 1 + 2 * (size_t)lg_n; j += n) { if (j == 0) sc[0] = ends[0]; else ends_to[j - 1] = ends[j]; }
     Fe<F> s = fe_one<F>(), sinv = fe_one<F>();
     for (int j = 0; j < lg_n; j++) {
         bool bit = (i >> (lg_n - 1 - j)) & 1;
