@@ -88,6 +88,7 @@ def test_hostpool_alternating_runs_under_tsan(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "hostpool_stress")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", os.path.join(root, "tests", "cpp", "hostpool_stress.cpp"), "-o", exe])
-    p = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}      # (scripts/sanitize_cpu.sh preloads the ASan runtime: not into a TSan binary)
+    p = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0 and "hostpool_stress ok" in p.stdout, p.stdout + p.stderr
     assert "ThreadSanitizer" not in p.stderr, p.stderr
